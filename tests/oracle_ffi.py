@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/build/liboracle_iris.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under iris_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "build", "liboracle_iris.so")
+
+TRIG_LIBM, TRIG_IRIS = 0, 1
+TRACE_MAX_DEPTH = 64
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("world_to_clip", C.c_float * 16), ("clip_to_world", C.c_float * 16)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "spp_total", "spp_begin", "spp_count", "seed",
+                                          "max_depth", "min_depth", "integrator")]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "bounces", "rays", "sphere_tests")]
+
+
+class Trace(C.Structure):
+    _fields_ = [("hero", C.c_float * 4), ("ray_o", C.c_float * 3), ("ray_d", C.c_float * 3),
+                ("radiance", C.c_float * 4), ("xyz", C.c_float * 3), ("n_hits", C.c_uint32),
+                ("hit_prim", C.c_int32 * TRACE_MAX_DEPTH), ("hit_t", C.c_float * TRACE_MAX_DEPTH),
+                ("draws", C.c_uint32)]
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile if the .so is missing (needs gcc)."""
+    src = os.path.join(ORACLE_DIR, "iris_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    u32 = C.c_uint32
+    sig = {
+        "orc_set_trig_mode": (None, [C.c_int]),
+        "orc_sinf": (C.c_float, [C.c_float]),
+        "orc_cosf": (C.c_float, [C.c_float]),
+        "orc_hash_u32": (u32, [u32, u32]),
+        "orc_hash_u32_to_f32": (C.c_float, [u32, u32]),
+        "orc_sobol_sample_4d": (None, [u32, u32, u32, fp]),
+        "orc_sobol_plain_u32": (u32, [u32, u32]),
+        "orc_lk_scramble": (u32, [u32, u32]),
+        "orc_sampler_draws": (None, [u32, u32, u32, u32, u32, fp]),
+        "orc_golden_ratio": (C.c_float, [u32, u32, u32, u32]),
+        "orc_wavelength_new": (None, [C.c_float, fp]),
+        "orc_offset_origin": (None, [fp, fp, fp]),
+        "orc_matrix_mul": (None, [fp, fp, fp]),
+        "orc_matrix_inverse": (C.c_int, [fp, fp]),
+        "orc_matrix_mul_point": (None, [fp, fp, fp]),
+        "orc_matrix_mul_vec": (None, [fp, fp, fp]),
+        "orc_matrix_projection": (None, [C.c_float] * 4 + [fp]),
+        "orc_matrix_translation": (None, [fp, fp]),
+        "orc_vec4_dot": (C.c_float, [fp, fp]),
+        "orc_vec4_sum": (C.c_float, [fp]),
+        "orc_fresnel_dielectric": (C.c_float, [C.c_float] * 3),
+        "orc_roughness_to_alpha": (C.c_float, [C.c_float]),
+        "orc_camera_new": (None, [fp, C.c_float, C.POINTER(Camera)]),
+        "orc_upsampled_evaluate_single": (C.c_float, [fp, C.c_float]),
+        "orc_xyz_from_wavelength": (None, [C.c_float, C.c_float, fp]),
+        "orc_xyz_to_rgb_hdr": (None, [fp, fp]),
+        "orc_cie_table": (fp, [C.c_int]),
+        "orc_scene_new": (C.c_void_p, []),
+        "orc_scene_free": (None, [C.c_void_p]),
+        "orc_scene_add_spectrum": (C.c_int, [C.c_void_p, u32] + [C.c_float] * 4),
+        "orc_scene_add_bsdf": (C.c_int, [C.c_void_p, u32, C.c_int, C.c_int, C.c_float, C.c_float]),
+        "orc_scene_add_sphere": (C.c_int, [C.c_void_p] + [C.c_float] * 4 + [C.c_int, C.c_int]),
+        "orc_scene_dummy": (None, [C.c_void_p]),
+        "orc_scene_num_prims": (u32, [C.c_void_p]),
+        "orc_scene_intersect": (C.c_int, [C.c_void_p, fp, fp, fp, fp, fp, fp, fp, C.POINTER(C.c_int)]),
+        "orc_trace_sample": (None, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), u32, u32, u32, C.POINTER(Trace)]),
+        "orc_pixel_xyz": (None, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), u32, u32, fp]),
+        "orc_render": (C.c_double, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_int, fp, fp, C.POINTER(Stats)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def f32a(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def set_trig_mode(mode):
+    lib().orc_set_trig_mode(mode)
+
+
+def camera_new(pos, aspect):
+    cam = Camera()
+    p = f32a(pos)
+    lib().orc_camera_new(_fp(p), C.c_float(aspect), C.byref(cam))
+    return cam
+
+
+def make_params(width, height, spp_total, spp_begin=0, spp_count=None, seed=123456789, max_depth=15, min_depth=2,
+                integrator=0):
+    return Params(width, height, spp_total, spp_begin, spp_total if spp_count is None else spp_count, seed,
+                  max_depth, min_depth, integrator)
+
+
+class OracleScene:
+    """Oracle-side scene built from an iris_amd.scene.Scene (flat description)."""
+
+    def __init__(self, flat=None):
+        self.h = lib().orc_scene_new()
+        if flat is not None:
+            self.load(flat)
+
+    def load(self, flat):
+        L = lib()
+        for kind, c0, c1, c2, hdr in flat.spectra:
+            L.orc_scene_add_spectrum(self.h, kind, c0, c1, c2, hdr)
+        for kind, a, b, p0, p1 in flat.bsdfs:
+            L.orc_scene_add_bsdf(self.h, kind, a, b, p0, p1)
+        light_spec = {prim: spec for spec, prim in flat.lights}
+        for i, (cx, cy, cz, r) in enumerate(flat.spheres):
+            # prim_light[i] >= 0 <=> the primitive has a light; the oracle's add_sphere appends the light
+            L.orc_scene_add_sphere(self.h, cx, cy, cz, r, int(flat.prim_material[i]),
+                                   int(light_spec[i]) if flat.prim_light[i] >= 0 else -1)
+
+    @classmethod
+    def dummy(cls):
+        s = cls()
+        lib().orc_scene_dummy(s.h)
+        return s
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_scene_free(self.h)
+            self.h = None
+
+    def intersect(self, o, d):
+        o, d = f32a(o), f32a(d)
+        t = C.c_float()
+        bf = C.c_int()
+        pt, n, tg, bt = (np.zeros(3, np.float32) for _ in range(4))
+        prim = lib().orc_scene_intersect(self.h, _fp(o), _fp(d), C.byref(t), _fp(pt), _fp(n), _fp(tg), _fp(bt), C.byref(bf))
+        return prim, t.value, pt, n, tg, bt, bool(bf.value)
+
+    def trace(self, cam, params, x, y, s):
+        tr = Trace()
+        lib().orc_trace_sample(self.h, C.byref(cam), C.byref(params), x, y, s, C.byref(tr))
+        return tr
+
+    def pixel_xyz(self, cam, params, x, y):
+        out = np.zeros(3, np.float32)
+        lib().orc_pixel_xyz(self.h, C.byref(cam), C.byref(params), x, y, _fp(out))
+        return out
+
+    def render(self, cam, params, nthreads=1, want_rgb=False):
+        n = params.width * params.height
+        xyz = np.zeros((params.height, params.width, 3), np.float32)
+        rgb = np.zeros((params.height, params.width, 3), np.float32) if want_rgb else None
+        st = Stats()
+        secs = lib().orc_render(self.h, C.byref(cam), C.byref(params), nthreads, _fp(xyz),
+                                _fp(rgb) if want_rgb else None, C.byref(st))
+        assert n * 3 == xyz.size
+        return xyz, rgb, secs, st
+
+
+def sampler_draws(x, y, s, seed, n):
+    out = np.zeros(n, np.float32)
+    lib().orc_sampler_draws(x, y, s, seed, n, _fp(out))
+    return out
+
+
+def sobol_sample_4d(index, dimset, seed):
+    out = np.zeros(4, np.float32)
+    lib().orc_sobol_sample_4d(index, dimset, seed, _fp(out))
+    return out
