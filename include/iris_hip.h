@@ -1,0 +1,210 @@
+/*
+ * iris_hip.h -- C ABI of libiris_hip.so, the MI355X (gfx950) implementation of
+ * the per-pixel path-tracing hot path of the iris spectral renderer.
+ *
+ * Where it sits in the reference (64/iris @ 2025-01-03, paths relative to
+ * src/): the reference calls `Integrator::radiance` once per camera sample
+ * (integrator/mod.rs:13-15) from the sample loop of `get_pixel_color`
+ * (tile.rs:127-166), which `TileData::render` drives per pixel
+ * (tile.rs:75-124) from the worker threads of main.rs:87-103.  A per-ray call
+ * is the wrong granularity for a GPU, so the boundary moves one level up:
+ * `iris_render*` replaces the whole `TileData::render` / `get_pixel_color` /
+ * `radiance` stack for a film and a range of sample indices, and returns what
+ * `get_pixel_color` returns per pixel (xyz_sum * 1/spp, tile.rs:165).
+ * Scene construction (scene.rs:31-110), the camera matrices (camera.rs:10-21)
+ * and image output (main.rs:116-123) stay on the host.
+ *
+ * Conventions: every function returns 0 on success or a negative IRIS_E_*
+ * code; no exception or abort crosses the ABI; the message for the last
+ * failure on a context is available from iris_last_error().  The caller owns
+ * every buffer it passes; the library copies scene data at upload and owns
+ * all device memory behind the opaque iris_ctx.  One iris_ctx drives one GPU;
+ * calls on one context must be serialised by the caller, different contexts
+ * may be used from different threads.
+ */
+#ifndef IRIS_HIP_H
+#define IRIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRIS_OK 0
+#define IRIS_E_ARG (-1)   /* invalid argument / scene description */
+#define IRIS_E_HIP (-2)   /* a HIP runtime call failed */
+#define IRIS_E_STATE (-3) /* call out of order (e.g. render before scene upload) */
+#define IRIS_E_LIMIT (-4) /* a documented size limit was exceeded */
+
+/* enum Bsdf, bsdf/mod.rs:49-55 (same order) */
+enum iris_bsdf_kind {
+    IRIS_BSDF_LAMBERTIAN = 0, /* lambertian.rs: spec_a = albedo */
+    IRIS_BSDF_MICROFACET = 1, /* microfacet.rs: spec_a = reflectance, p0 = alpha_x, p1 = alpha_y
+                                 (already mapped from roughness by iris_roughness_to_alpha) */
+    IRIS_BSDF_SPECULAR = 2,   /* specular.rs: spec_a = reflected_color */
+    IRIS_BSDF_FRESNEL = 3,    /* fresnel.rs: spec_a = reflected_color, spec_b = transmitted_color,
+                                 p0 = base_ior, p1 = dispersion */
+    IRIS_BSDF_NULL = 4        /* null.rs (unreachable!() in the reference): absorbs */
+};
+
+/* enum Spectrum, spectrum/mod.rs:25-28 (same order); HDR variant: upsample.rs:27-42 */
+enum iris_spectrum_kind {
+    IRIS_SPEC_UPSAMPLED = 0,    /* c0,c1,c2 = sigmoid-polynomial coefficients (upsample.rs:12-24) */
+    IRIS_SPEC_CONSTANT = 1,     /* c0 = value (constant.rs) */
+    IRIS_SPEC_UPSAMPLED_HDR = 2 /* c0,c1,c2 + hdr = hdr_coefficient */
+};
+
+/* integrator/mod.rs:8-11; the reference picks one at compile time (main.rs:31) */
+enum iris_integrator {
+    IRIS_INT_HWSS_NAIVE = 0, /* hwss_naive.rs (the reference's default) */
+    IRIS_INT_HWSS_SLOW = 1,  /* hwss_slow.rs */
+    IRIS_INT_SWSS_NAIVE = 2, /* swss_naive.rs */
+    IRIS_INT_SWSS_SLOW = 3   /* swss_slow.rs */
+};
+
+typedef struct iris_ctx iris_ctx;
+
+/* shape/sphere.rs:7-11 */
+typedef struct { float cx, cy, cz, r; } iris_sphere;
+typedef struct { uint32_t kind; float c0, c1, c2, hdr; } iris_spectrum;
+typedef struct { uint32_t kind; uint32_t spec_a, spec_b; float p0, p1; } iris_bsdf;
+/* scene.rs:24: lights: Vec<PrimIndex<Spectrum>> (types.rs:1-5) */
+typedef struct { uint32_t spectrum; uint32_t prim; } iris_light;
+
+/* Flattened `Scene` (scene.rs:22-28).  prim_material[i] / prim_light[i] are
+ * Primitive::material_index / light_index (shape/mod.rs:55-60), -1 for None.
+ * Primitive order is the order of the reference's `primitives` Vec: the
+ * closest-hit scan keeps the lowest index on ties (scene.rs:116-132). */
+typedef struct {
+    uint32_t n_prims;
+    const iris_sphere *spheres;
+    const int32_t *prim_material;
+    const int32_t *prim_light;
+    uint32_t n_bsdfs;
+    const iris_bsdf *bsdfs;
+    uint32_t n_spectra;
+    const iris_spectrum *spectra;
+    uint32_t n_lights;
+    const iris_light *lights;
+} iris_scene_desc;
+
+/* camera.rs:3-7; matrices row-major (m[i][j] at 4*i+j) */
+typedef struct {
+    float position[3];
+    float clip_to_world[16];
+} iris_camera;
+
+/* The compile-time constants of the reference, as run-time parameters:
+ * WIDTH/HEIGHT/TOTAL_SPP (main.rs:27-29), SEED (tile.rs:15),
+ * MAX_DEPTH/MIN_DEPTH (hwss_naive.rs:16-17), CurrentIntegrator (main.rs:31).
+ * spp_begin/spp_count are get_pixel_color's samples_so_far/samples_this_iter
+ * (tile.rs:130-131): the call renders sample indices
+ * [spp_begin, spp_begin+spp_count) of every pixel and scales the sum by
+ * 1/spp_total, so films of disjoint ranges add up to the full render. */
+typedef struct {
+    uint32_t width, height;
+    uint32_t spp_total;
+    uint32_t spp_begin;
+    uint32_t spp_count;
+    uint32_t seed;
+    uint32_t max_depth;
+    uint32_t min_depth;
+    uint32_t integrator; /* enum iris_integrator */
+} iris_render_params;
+
+/* Exact device counters of the last iris_render* call (the inputs of the
+ * flop model in DESIGN.md) and its timing. */
+typedef struct {
+    uint64_t samples;      /* camera samples traced */
+    uint64_t bounces;      /* surface interactions shaded */
+    uint64_t rays;         /* Scene scans: intersection + ray_hits_point + ray_hits_object */
+    uint64_t sphere_tests; /* Sphere::intersect evaluations */
+    double kernel_ms;      /* HIP-event time of the path-tracing kernels (sum over launches) */
+    double resolve_ms;     /* HIP-event time of the film resolve kernels */
+    uint32_t launches;     /* path-tracing kernel launches */
+    uint32_t chunks;       /* sample-range chunks the render was split into */
+} iris_stats;
+
+/* One traced camera sample, for stage-level parity tests (iris_dbg_trace). */
+#define IRIS_TRACE_MAX_DEPTH 64
+typedef struct {
+    float hero[4];
+    float ray_o[3], ray_d[3];
+    float radiance[4];
+    float xyz[3];
+    uint32_t n_hits;
+    int32_t hit_prim[IRIS_TRACE_MAX_DEPTH];
+    float hit_t[IRIS_TRACE_MAX_DEPTH];
+    uint32_t draws;
+} iris_trace;
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Creates a context on HIP device `device` (replaces nothing in the reference;
+ * the Rust side would hold it next to `Render`, main.rs:33-41). */
+int iris_ctx_create(int device, iris_ctx **out);
+void iris_ctx_destroy(iris_ctx *ctx);
+const char *iris_last_error(const iris_ctx *ctx);
+
+/* Tuning knobs, all optional.  Keys:
+ *   "blocks_per_cu"   persistent workgroups per CU (default 4)
+ *   "slots_per_block" path-state slots per workgroup (default 1024)
+ *   "result_bytes"    cap on the per-sample result buffer (default 64 GiB)
+ *   "multi_kernel"    1: launch the two stages as separate kernels (for profiling);
+ *                     0: one persistent kernel (default)
+ */
+int iris_ctx_set_option(iris_ctx *ctx, const char *key, int64_t value);
+
+/* ---- scene / camera --------------------------------------------------- */
+
+/* Copies the scene to the GPU.  Replaces holding `Render.scene` (main.rs:37) by reference. */
+int iris_scene_upload(iris_ctx *ctx, const iris_scene_desc *scene);
+
+/* Host-side restatement of Camera::new (camera.rs:10-21; matrix.rs:32-141,206-225). */
+int iris_camera_new(const float position[3], float aspect_ratio, iris_camera *out);
+
+/* ggx::roughness_to_alpha (sampling/ggx.rs:66-73), applied by MicrofacetBsdf::new
+ * (bsdf/microfacet.rs:21-29) at scene construction. */
+float iris_roughness_to_alpha(float roughness);
+
+/* ---- the hot path ----------------------------------------------------- */
+
+/* Renders sample indices [spp_begin, spp_begin+spp_count) of every pixel and
+ * writes `xyz_sum * (1/spp_total)` per pixel -- the value get_pixel_color
+ * returns (tile.rs:127-166) -- as 3 f32 per pixel at 3*(x + y*width)
+ * (film indexing of main.rs:120-122).  Samples of a pixel are summed in
+ * ascending sample-index order, as tile.rs:144-163 does.
+ * iris_render: out_xyz is HOST memory (width*height*3 floats).
+ * iris_render_device: d_out_xyz is DEVICE memory on the context's GPU; work is
+ * enqueued on `stream` (a hipStream_t, NULL = default stream) and the call
+ * returns after the stream has finished it. */
+int iris_render(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params, float *out_xyz);
+int iris_render_device(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params,
+                       float *d_out_xyz, void *stream);
+
+/* XYZ -> linear RGB, clamped at 0: Xyz::to_rgb_hdr (color.rs:36-41) + the clamp of tile.rs:108-109.
+ * Host arrays of 3*n_pixels floats. */
+int iris_film_to_rgb(const float *xyz, size_t n_pixels, float *rgb);
+
+int iris_get_stats(const iris_ctx *ctx, iris_stats *out);
+
+/* ---- stage-level entry points for parity tests ------------------------ */
+/* xys: n triplets (x, y, sample_index). */
+
+/* First `ndraws` values of Sampler::gen_0_1 (sampling/sampler.rs:13-50) for each triplet: out[n][ndraws]. */
+int iris_dbg_sampler(iris_ctx *ctx, uint32_t n, const uint32_t *xys, uint32_t seed, uint32_t ndraws, float *out);
+/* Camera sample of tile.rs:134-157: hero[n][4], ray_o[n][3], ray_d[n][3]. */
+int iris_dbg_raygen(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params, uint32_t n,
+                    const uint32_t *xys, float *hero, float *ray_o, float *ray_d);
+/* Scene::intersection (scene.rs:116-132) on explicit rays: prim[n] (-1 = miss), t[n]. */
+int iris_dbg_intersect(iris_ctx *ctx, uint32_t n, const float *ray_o, const float *ray_d, int32_t *prim, float *t);
+/* One full camera sample per triplet through the same device code the render uses. */
+int iris_dbg_trace(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params, uint32_t n,
+                   const uint32_t *xys, iris_trace *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+"""Builds libiris_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m iris_amd.build [--force]
+
+Flags that matter for correctness:
+  -ffp-contract=off   one IEEE-754 f32 operation per source operation (the reference's Rust never
+                      contracts a*b+c); the film is compared bit for bit with a scalar CPU evaluation.
+  hipcc's default for HIP, -fhip-fp32-correctly-rounded-divide-sqrt, is left ON (IEEE divide/sqrt),
+  and f32 denormals are left enabled (the gfx9 default).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libiris_hip.so")
+SOURCES = [os.path.join(CSRC, "iris_kernels.hip"), os.path.join(CSRC, "iris_host.cpp")]
+DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "tables", "cie1931.inc"),
+                  os.path.join(CSRC, "tables", "sobol_rev16.inc"), os.path.join(HERE, "..", "include", "iris_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, extra=()):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", LIB_PATH] + SOURCES
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
+    print(path)

@@ -1,0 +1,810 @@
+// iris_device.h -- gfx950 device functions of the iris path-tracing hot path.
+//
+// Everything here runs per lane on a register-resident path state; the kernels
+// in iris_kernels.hip move that state between HBM/L2-resident SoA pools, LDS
+// queues and registers.  Compile with -ffp-contract=off: each f32 operation
+// below is one IEEE-754 operation in the order the reference writes it
+// (file:line citations are relative to the reference's src/), which is what
+// makes the film bit-comparable with a scalar CPU evaluation.  The only fused
+// operations are the explicit fmaf calls of the sigmoid spectrum
+// (spectrum/upsample.rs:19-23) and the f64 fma chain of iris_sin/iris_cos
+// (docs/SPEC.md), both fused in the reference/specification as well.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/iris_hip.h"
+
+#define IRIS_TABLE_QUAL __device__ const
+#include "tables/cie1931.inc"
+#define IRIS_SOBOL_SETS 64u
+
+namespace iris {
+
+#define IRIS_DEV __device__ __forceinline__
+#define PI_F 3.14159274101257324219f
+
+// ---------------------------------------------------------------- scalars
+// f32::max / f32::min (IEEE maxNum/minNum: a NaN operand is ignored)
+IRIS_DEV float rmax(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
+IRIS_DEV float rmin(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
+// f32::clamp (NaN stays NaN)
+IRIS_DEV float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// Rust `as usize` on a value that is then used as a small index: saturating, NaN -> 0
+IRIS_DEV uint32_t f_as_index(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+// Rust `as i32`: saturating, NaN -> 0
+IRIS_DEV int32_t f_as_i32(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 0x7fffffff;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)f;
+}
+IRIS_DEV float rsqrt_exact(float x) { return __builtin_sqrtf(x); }  // correctly rounded (hipcc default for HIP)
+IRIS_DEV float fabs_(float x) { return __builtin_fabsf(x); }
+
+// ---------------------------------------------------------------- sin / cos (docs/SPEC.md)
+// f64 Cody-Waite reduction by pi/2 + fdlibm kernel polynomials, explicit fma chain,
+// one rounding to f32.  Within 1 ulp of (and almost always equal to) a correctly
+// rounded libm sinf/cosf, which is what the reference's f32::sin/cos call.
+IRIS_DEV double trig_reduce(double xd, int &quadrant) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    double kd = __builtin_rint(xd * TWO_OVER_PI);
+    double r = __builtin_fma(-kd, PIO2_HI, xd);
+    r = __builtin_fma(-kd, PIO2_LO, r);
+    quadrant = ((int)kd) & 3;
+    return r;
+}
+IRIS_DEV double trig_ksin(double r) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = r * r;
+    double p = __builtin_fma(z, S6, S5);
+    p = __builtin_fma(z, p, S4);
+    p = __builtin_fma(z, p, S3);
+    p = __builtin_fma(z, p, S2);
+    p = __builtin_fma(z, p, S1);
+    return __builtin_fma(r * z, p, r);
+}
+IRIS_DEV double trig_kcos(double r) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = r * r;
+    double p = __builtin_fma(z, C6, C5);
+    p = __builtin_fma(z, p, C4);
+    p = __builtin_fma(z, p, C3);
+    p = __builtin_fma(z, p, C2);
+    p = __builtin_fma(z, p, C1);
+    return __builtin_fma(z * z, p, __builtin_fma(z, -0.5, 1.0));
+}
+// sin and cos of the same argument share the reduction and both kernels.
+IRIS_DEV void iris_sincos(float x, float &s_out, float &c_out) {
+    double xd = (double)x;
+    if (!(__builtin_fabs(xd) < 1.0e5)) { s_out = x - x; c_out = x - x; return; }
+    int q;
+    double r = trig_reduce(xd, q);
+    double ks = trig_ksin(r), kc = trig_kcos(r);
+    double s = (q & 1) ? kc : ks;
+    double c = (q & 1) ? ks : kc;
+    s_out = (float)((q & 2) ? -s : s);
+    c_out = (float)(((q + 1) & 2) ? -c : c);
+}
+
+// ---------------------------------------------------------------- vectors (math/vec3.rs, point3.rs, vec4.rs)
+struct V3 { float x, y, z; };
+struct F4 { float v[4]; };  // Vec4 / SpectralSample / PdfSet / Wavelength; always indexed with constants
+
+IRIS_DEV V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+IRIS_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+IRIS_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+IRIS_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+IRIS_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+IRIS_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+IRIS_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+IRIS_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vec3.rs:45-48
+IRIS_DEV V3 cross(V3 a, V3 b) {                                                   // vec3.rs:50-57
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+IRIS_DEV float len_squared(V3 a) { return dot(a, a); }
+IRIS_DEV float len(V3 a) { return rsqrt_exact(len_squared(a)); }
+IRIS_DEV V3 normalize(V3 a) { return a / len(a); }  // vec3.rs:67-70: a true divide per component
+IRIS_DEV float distance_squared(V3 a, V3 b) { return len_squared(a - b); }
+IRIS_DEV float distance(V3 a, V3 b) { return rsqrt_exact(distance_squared(a, b)); }
+IRIS_DEV V3 face_forward(V3 s, V3 n) { return dot(s, n) >= 0.0f ? s : -s; }  // vec3.rs:105-111
+
+// vec3.rs:77-85 (divides by x^2+z^2, not its square root -- as written in the reference)
+IRIS_DEV void coordinate_system_from_unit(V3 s, V3 &v2, V3 &v3o) {
+    if (fabs_(s.x) > fabs_(s.y)) v2 = v3(-s.z, 0.0f, s.x) / (s.x * s.x + s.z * s.z);
+    else v2 = v3(0.0f, s.z, -s.y) / (s.y * s.y + s.z * s.z);
+    v3o = cross(s, v2);
+}
+
+// shading-space trigonometry, vec3.rs:301-355
+IRIS_DEV float cos_theta(V3 w) { return w.z; }
+IRIS_DEV float cos_2_theta(V3 w) { return w.z * w.z; }
+IRIS_DEV float sin_2_theta(V3 w) { return rmax(1.0f - cos_2_theta(w), 0.0f); }
+IRIS_DEV float sin_theta(V3 w) { return rsqrt_exact(sin_2_theta(w)); }
+IRIS_DEV float tan_theta(V3 w) { return sin_theta(w) / cos_theta(w); }
+IRIS_DEV float tan_2_theta(V3 w) { return sin_2_theta(w) / cos_2_theta(w); }
+IRIS_DEV float cos_phi(V3 w) { float st = sin_theta(w); return st == 0.0f ? 0.0f : rclamp(w.x / st, -1.0f, 1.0f); }
+IRIS_DEV float sin_phi(V3 w) { float st = sin_theta(w); return st == 0.0f ? 0.0f : rclamp(w.y / st, -1.0f, 1.0f); }
+IRIS_DEV float cos_2_phi(V3 w) { float c = cos_phi(w); return c * c; }
+IRIS_DEV float sin_2_phi(V3 w) { float s = sin_phi(w); return s * s; }
+IRIS_DEV bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }
+
+IRIS_DEV F4 f4(float a, float b, float c, float d) { F4 r = {{a, b, c, d}}; return r; }
+IRIS_DEV F4 splat(float x) { return f4(x, x, x, x); }
+#define IRIS_F4_OP(name, expr)                                                  \
+    IRIS_DEV F4 name(F4 a, F4 b) { F4 r; _Pragma("unroll") for (int i = 0; i < 4; i++) { float x = a.v[i], y = b.v[i]; r.v[i] = (expr); } return r; }
+IRIS_F4_OP(operator+, x + y)
+IRIS_F4_OP(operator*, x * y)
+IRIS_F4_OP(operator/, x / y)
+IRIS_DEV F4 operator*(F4 a, float s) { return a * splat(s); }
+IRIS_DEV F4 operator*(float s, F4 a) { return splat(s) * a; }
+IRIS_DEV F4 operator/(F4 a, float s) { return a / splat(s); }
+IRIS_DEV F4 operator/(float s, F4 a) { return splat(s) / a; }
+IRIS_DEV F4 operator+(float s, F4 a) { return splat(s) + a; }
+IRIS_DEV float hero(F4 a) { return a.v[0]; }
+// vec4.rs:55-57: f32x4::reduce_sum is the ordered reduction starting from -0.0
+IRIS_DEV float sum(F4 a) { return ((((-0.0f) + a.v[0]) + a.v[1]) + a.v[2]) + a.v[3]; }
+
+// ---------------------------------------------------------------- rays (math/ray.rs)
+#define IRIS_RAY_EPSILON 0.001f  // ray.rs:5
+struct Ray { V3 o, d; };
+
+// ray.rs:61-85: Waechter-Binder integer-ulp origin offset
+IRIS_DEV float offset_component(float p, float n) {
+    const float ORIGIN = 1.0f / 32.0f, FLOAT_SCALE = 1.0f / 65536.0f, INT_SCALE = 256.0f;
+    uint32_t off = (uint32_t)f_as_i32(INT_SCALE * n);
+    uint32_t bits = __float_as_uint(p) + (p < 0.0f ? (0u - off) : off);
+    return fabs_(p) < ORIGIN ? p + FLOAT_SCALE * n : __uint_as_float(bits);
+}
+IRIS_DEV V3 offset_origin(V3 p, V3 n) { return v3(offset_component(p.x, n.x), offset_component(p.y, n.y), offset_component(p.z, n.z)); }
+IRIS_DEV Ray ray_new(V3 o, V3 d) { Ray r = {o, normalize(d)}; return r; }  // ray.rs:14-19
+IRIS_DEV Ray ray_spawn(V3 o, V3 d, V3 normal) {                             // ray.rs:21-32
+    V3 o2 = dot(d, normal) < 0.0f ? offset_origin(o, -normal) : offset_origin(o, normal);
+    Ray r = {o2, normalize(d)};
+    return r;
+}
+IRIS_DEV Ray ray_spawn_to(V3 o, V3 p, V3 normal) {  // ray.rs:34-45 (direction from the OFFSET origin)
+    V3 o2 = dot(p - o, normal) < 0.0f ? offset_origin(o, -normal) : offset_origin(o, normal);
+    Ray r = {o2, normalize(p - o2)};
+    return r;
+}
+
+// ---------------------------------------------------------------- math/mod.rs
+IRIS_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {  // mod.rs:35-59
+    cos_theta_i = rclamp(cos_theta_i, -1.0f, 1.0f);
+    float ei, et, ci;
+    if (cos_theta_i > 0.0f) { ei = eta_i; et = eta_t; ci = cos_theta_i; }
+    else { ei = eta_t; et = eta_i; ci = fabs_(cos_theta_i); }
+    float sin_theta_i = rsqrt_exact(rmax(1.0f - ci * ci, 0.0f));
+    float sin_theta_t = ei / et * sin_theta_i;
+    if (sin_theta_t >= 1.0f) return 1.0f;
+    float cos_theta_t = rsqrt_exact(rmax(1.0f - sin_theta_t * sin_theta_t, 0.0f));
+    float r_par = ((et * ci) - (ei * cos_theta_t)) / ((et * ci) + (ei * cos_theta_t));
+    float r_perp = ((ei * ci) - (et * cos_theta_t)) / ((ei * ci) + (et * cos_theta_t));
+    return (r_par * r_par + r_perp * r_perp) / 2.0f;
+}
+IRIS_DEV bool refract(V3 wi, V3 n, float eta, V3 &out) {  // mod.rs:61-72
+    float cos_theta_i = dot(n, wi);
+    float sin_2_theta_i = rmax(1.0f - cos_theta_i * cos_theta_i, 0.0f);
+    float sin_2_theta_t = eta * eta * sin_2_theta_i;
+    if (sin_2_theta_t >= 1.0f) return false;
+    float cos_theta_t = rsqrt_exact(1.0f - sin_2_theta_t);
+    out = eta * (-wi) + n * (eta * cos_theta_i - cos_theta_t);
+    return true;
+}
+
+// ---------------------------------------------------------------- sampler (sampling/sampler.rs)
+IRIS_DEV uint32_t hash_u32(uint32_t n, uint32_t seed) {  // sampler.rs:74-83
+    uint32_t h = n;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { h *= 1936502639u; h ^= h >> 16; h ^= seed; }
+    return h;
+}
+IRIS_DEV float hash_u32_to_f32(uint32_t n, uint32_t seed) {  // sampler.rs:85-88
+    return (float)hash_u32(n, seed) * (1.0f / 4294967296.0f);
+}
+IRIS_DEV uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+IRIS_DEV uint32_t lk_scramble(uint32_t n, uint32_t seed) {
+    n ^= n * 0x3d20adeau; n += seed; n *= (seed >> 16) | 1u; n ^= n * 0x05526c56u; n ^= n * 0x53a22864u;
+    return n;
+}
+IRIS_DEV float unit_float_from_bits(uint32_t v) { return __uint_as_float((v >> 9) | 0x3f800000u) - 1.0f; }
+
+// Sobol direction vectors in LDS: sobol_lds[bit * 64 + set] = the four 16-bit reversed vectors of
+// (set, bit) packed as {d0 | d1 << 16, d2 | d3 << 16}.  Bit-major so that lanes sitting at different
+// dimension sets hit different banks.
+typedef const uint2 *SobolLds;
+
+// This build's Owen-scrambled Sobol (docs/SPEC.md); stands where the reference calls the external
+// crate: sobol::sample_4d(index, dimension_set, seed), sampler.rs:30-34.
+IRIS_DEV void sobol_sample_4d(SobolLds tab, uint32_t index, uint32_t set, uint32_t seed, float out[4]) {
+    uint32_t shuffled_rev = lk_scramble(__builtin_bitreverse32(index), lowbias32(seed));
+    uint32_t x01 = 0u, x23 = 0u;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; b++) {
+        uint32_t m = (uint32_t)((int32_t)(shuffled_rev << b) >> 31);  // all ones iff bit (31-b) is set
+        uint2 v = tab[b * IRIS_SOBOL_SETS + set];
+        x01 ^= v.x & m;
+        x23 ^= v.y & m;
+    }
+    uint32_t xr[4] = {x01 & 0xffffu, x01 >> 16, x23 & 0xffffu, x23 >> 16};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        uint32_t dseed = lowbias32(seed ^ (0x9e3779b9u * (4u * set + k + 1u)));
+        out[k] = unit_float_from_bits(__builtin_bitreverse32(lk_scramble(xr[k], dseed)));
+    }
+}
+
+// sampler.rs:4-10.  The 4-entry buffer is a shift register (q2 is popped next) so that no
+// runtime-indexed array is needed.
+struct Sampler {
+    uint32_t scramble, dimension, index;
+    float q0, q1, q2;
+    uint32_t in_buffer;
+    uint32_t draws;
+};
+IRIS_DEV Sampler sampler_new(uint32_t x, uint32_t y, uint32_t sample_index, uint32_t seed) {  // sampler.rs:13-21
+    Sampler s;
+    s.scramble = hash_u32(x ^ (y << 16), seed);
+    s.dimension = 0u; s.index = sample_index;
+    s.q0 = s.q1 = s.q2 = 0.0f; s.in_buffer = 0u; s.draws = 0u;
+    return s;
+}
+__device__ __noinline__ float sampler_refill(SobolLds tab, Sampler &s) {  // sampler.rs:27-46
+    float b[4];
+    if (s.dimension < IRIS_SOBOL_SETS) {
+        sobol_sample_4d(tab, s.index, s.dimension, hash_u32(s.dimension, s.scramble), b);
+    } else {  // sampler.rs:36-41 (from set 64 on: docs/SPEC.md)
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) b[k] = hash_u32_to_f32((s.dimension + k) ^ (s.index << 16), s.scramble);
+    }
+    s.dimension += 1u;
+    s.in_buffer = 3u;
+    s.q0 = b[0]; s.q1 = b[1]; s.q2 = b[2];
+    return b[3];
+}
+IRIS_DEV float gen_0_1(SobolLds tab, Sampler &s) {  // sampler.rs:23-50: values pop in reverse
+    s.draws++;
+    if (s.in_buffer > 0u) {
+        float r = s.q2;
+        s.q2 = s.q1; s.q1 = s.q0;
+        s.in_buffer -= 1u;
+        return r;
+    }
+    return sampler_refill(tab, s);
+}
+IRIS_DEV float gen_golden_ratio(const Sampler &s) {  // sampler.rs:65-71 (u32::MAX as f32 == 2^32)
+    uint32_t u = (s.index + s.scramble) * 2654435769u;
+    return (float)u / 4294967296.0f;
+}
+
+// ---------------------------------------------------------------- warps (sampling/mod.rs), MIS (mis.rs)
+IRIS_DEV float pdf_cone(float cos_theta_max) { return 1.0f / (2.0f * PI_F * (1.0f - cos_theta_max)); }  // mod.rs:22-24
+IRIS_DEV V3 unit_sphere(float r1, float r2) {                                                              // mod.rs:26-31
+    float z = 1.0f - 2.0f * r1;
+    float r = rsqrt_exact(rmax(1.0f - z * z, 0.0f));
+    float phi = 2.0f * PI_F * r2;
+    float s, c;
+    iris_sincos(phi, s, c);
+    return v3(r * c, r * s, z);
+}
+IRIS_DEV V3 cosine_unit_hemisphere(float r1, float r2) {  // mod.rs:33-54
+    float x_off = 2.0f * r1 - 1.0f, y_off = 2.0f * r2 - 1.0f;
+    float x = 0.0f, y = 0.0f;
+    if (!(x_off == 0.0f && y_off == 0.0f)) {
+        float r, theta;
+        if (fabs_(x_off) > fabs_(y_off)) { r = x_off; theta = PI_F / 4.0f * (y_off / x_off); }
+        else { r = y_off; theta = (PI_F / 2.0f) - (PI_F / 4.0f) * (x_off / y_off); }
+        float s, c;
+        iris_sincos(theta, s, c);
+        x = r * c; y = r * s;
+    }
+    float z = rsqrt_exact(rmax(1.0f - x * x - y * y, 0.0f));
+    return v3(x, y, z);
+}
+IRIS_DEV float balance_heuristic_1(F4 f) { return hero(f) / sum(f); }             // mis.rs:3-5
+IRIS_DEV float balance_heuristic_2(F4 f, F4 g) { return hero(f) / sum(f + g); }  // mis.rs:8-10
+
+// ---------------------------------------------------------------- spectra, colour
+#define LAMBDA_MIN_NM 360.0f
+#define LAMBDA_MAX_NM 830.0f
+#define LAMBDA_RANGE_NM (LAMBDA_MAX_NM - LAMBDA_MIN_NM)
+
+IRIS_DEV float rotate_n(float h, uint32_t n) {  // wavelength.rs:55-64
+    float lambda = h + (LAMBDA_RANGE_NM / 4.0f) * (float)n;
+    return lambda >= LAMBDA_MAX_NM ? lambda - LAMBDA_RANGE_NM : lambda;
+}
+IRIS_DEV F4 wavelength_new(float h) { return f4(h, rotate_n(h, 1), rotate_n(h, 2), rotate_n(h, 3)); }  // wavelength.rs:14-24
+
+IRIS_DEV float spectrum_evaluate_single(const iris_spectrum &s, float lambda) {
+    if (s.kind == IRIS_SPEC_CONSTANT) return s.c0;  // constant.rs:15-23
+    // upsample.rs:18-24 / :35-41 -- explicit fused multiply-adds in the reference
+    float x = __builtin_fmaf(__builtin_fmaf(s.c0, lambda, s.c1), lambda, s.c2);
+    float y = 1.0f / rsqrt_exact(__builtin_fmaf(x, x, 1.0f));
+    float v = __builtin_fmaf(0.5f * x, y, 0.5f);
+    return s.kind == IRIS_SPEC_UPSAMPLED ? v : s.hdr * v;
+}
+IRIS_DEV F4 spectrum_evaluate(const iris_spectrum &s, F4 wl) {  // spectrum/mod.rs:16-20
+    return f4(spectrum_evaluate_single(s, wl.v[0]), spectrum_evaluate_single(s, wl.v[1]),
+              spectrum_evaluate_single(s, wl.v[2]), spectrum_evaluate_single(s, wl.v[3]));
+}
+// sample.rs:45-52 + color.rs:21-34: truncating table lookup per wavelength, summed a+b+c+d
+IRIS_DEV V3 spectral_to_xyz(F4 value, F4 wl) {
+    const float CIE_Y_INTEGRAL = 116.661843131358f;
+    const float scale = (LAMBDA_MAX_NM - LAMBDA_MIN_NM) / CIE_Y_INTEGRAL;
+    float X[4], Y[4], Z[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t index = f_as_index(wl.v[k]) - 360u;
+        if (index > 470u) index = 470u;  // the reference indexes unchecked; a valid path never leaves 360..830
+        float v = value.v[k] * scale;
+        X[k] = IRIS_CIE_X[index] * v;
+        Y[k] = IRIS_CIE_Y[index] * v;
+        Z[k] = IRIS_CIE_Z[index] * v;
+    }
+    return v3(((X[0] + X[1]) + X[2]) + X[3], ((Y[0] + Y[1]) + Y[2]) + Y[3], ((Z[0] + Z[1]) + Z[2]) + Z[3]);
+}
+
+// ---------------------------------------------------------------- scene on the device
+struct SceneDev {
+    const float4 *spheres;      // (cx, cy, cz, r), primitive order
+    const int2 *prim_info;      // (material_index, light_index), -1 = None
+    const iris_bsdf *bsdfs;
+    const iris_spectrum *spectra;
+    const iris_light *lights;
+    uint32_t n_prims, n_lights;
+};
+
+// shape/mod.rs:14-38
+struct Hit { V3 point, normal, tangeant, bitangeant; bool back_face; };
+IRIS_DEV V3 world_to_shading(const Hit &h, V3 w) { return v3(dot(h.bitangeant, w), dot(h.tangeant, w), dot(h.normal, w)); }
+IRIS_DEV V3 shading_to_world(const Hit &h, V3 s) {
+    return v3(h.bitangeant.x * s.x + h.tangeant.x * s.y + h.normal.x * s.z,
+              h.bitangeant.y * s.x + h.tangeant.y * s.y + h.normal.y * s.z,
+              h.bitangeant.z * s.x + h.tangeant.z * s.y + h.normal.z * s.z);
+}
+
+// sphere.rs:26-35 + :53: the ray parameter of the first root > 0, or a negative number for None
+IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
+    V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
+    float half_b = dot(ray.d, oc);
+    float c = len_squared(oc) - sp.w * sp.w;
+    float discrim = half_b * half_b - a * c;
+    float t = -1.0f;
+    if (discrim > 0.0f) {
+        float root = rsqrt_exact(discrim);
+        float temp = (-half_b - root) / a;
+        if (!(temp > 0.0f)) temp = (-half_b + root) / a;
+        if (temp > 0.0f) t = temp;
+    }
+    return t;
+}
+// sphere.rs:36-40: the shading frame of a hit at parameter t (built once, for the winner only)
+IRIS_DEV Hit sphere_frame(float4 sp, const Ray &ray, float t) {
+    Hit h;
+    h.point = ray.o + ray.d * t;
+    h.normal = (h.point - v3(sp.x, sp.y, sp.z)) / sp.w;
+    h.tangeant = normalize(cross(v3(0.0f, 1.0f, 0.0f), h.normal));
+    h.bitangeant = cross(h.normal, h.tangeant);
+    h.back_face = dot(h.normal, ray.d) >= 0.0f;
+    return h;
+}
+
+// The sphere list as the scans see it: the whole list in LDS when it fits, else streamed through an
+// LDS window chunk by chunk by the whole workgroup.
+struct SphereStage {
+    float4 *lds;           // window
+    uint32_t cap;          // window capacity in spheres
+    bool resident;         // n_prims <= cap and the window already holds the list
+};
+
+// Scene::intersection / ray_hits_point / ray_hits_object all reduce to this scan (scene.rs:116-166):
+// closest t > 0 over all primitives in index order, strict '<' so the lowest index wins ties.
+// Must be called by every thread of the workgroup (inactive threads pass active=false) because a
+// list larger than the LDS window is staged cooperatively.
+IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool active, const Ray &ray, float &t_out, int &prim_out) {
+    float closest_t = __builtin_inff();
+    int closest = -1;
+    float a = len_squared(ray.d);  // sphere.rs:27 (loop-invariant)
+    if (st.resident) {
+        if (active) {
+            for (uint32_t i = 0; i < sc.n_prims; i++) {
+                float t = sphere_hit_t(st.lds[i], ray, a);
+                if (t > 0.0f && t < closest_t) { closest_t = t; closest = (int)i; }
+            }
+        }
+    } else {
+        for (uint32_t base = 0; base < sc.n_prims; base += st.cap) {
+            uint32_t n = sc.n_prims - base < st.cap ? sc.n_prims - base : st.cap;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) st.lds[i] = sc.spheres[base + i];
+            __syncthreads();
+            if (active) {
+                for (uint32_t i = 0; i < n; i++) {
+                    float t = sphere_hit_t(st.lds[i], ray, a);
+                    if (t > 0.0f && t < closest_t) { closest_t = t; closest = (int)(base + i); }
+                }
+            }
+        }
+    }
+    t_out = closest_t;
+    prim_out = closest;
+}
+
+// ---------------------------------------------------------------- sphere light (shape/sphere.rs:77-162)
+IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, SobolLds tab, Sampler &smp, V3 &p_out, float &pdf_out) {
+    float u0 = gen_0_1(tab, smp);
+    float u1 = gen_0_1(tab, smp);
+    V3 position = v3(sp.x, sp.y, sp.z);
+    float radius = sp.w;
+    V3 point = hit.back_face ? offset_origin(hit.point, -hit.normal) : offset_origin(hit.point, hit.normal);
+    if (distance_squared(position, point) <= radius * radius) {
+        V3 light_normal = unit_sphere(u0, u1);
+        V3 light_point = position + radius * light_normal;
+        float area = 4.0f * PI_F * (radius * radius);
+        float pdf = distance_squared(light_point, point) / (dot(light_normal, normalize(light_point - point)) * area);
+        p_out = light_point;
+        pdf_out = rmax(pdf, 0.001f);
+        return;
+    }
+    float dc = distance(position, hit.point);
+    V3 wc = normalize(position - hit.point);
+    V3 wc_x, wc_y;
+    coordinate_system_from_unit(wc, wc_x, wc_y);
+    float sin_theta_max = radius / dc;
+    float sin_theta_max_2 = sin_theta_max * sin_theta_max;
+    float cos_theta_max = rsqrt_exact(rmax(1.0f - sin_theta_max_2, 0.0f));
+    float sin_theta_2, cos_theta_;
+    if (sin_theta_max_2 < 0.00068523f) {
+        sin_theta_2 = sin_theta_max_2 * u0;
+        cos_theta_ = rsqrt_exact(rmax(1.0f - sin_theta_2, 0.0f));
+    } else {
+        cos_theta_ = (cos_theta_max - 1.0f) * u0 + 1.0f;
+        sin_theta_2 = 1.0f - cos_theta_ * cos_theta_;
+    }
+    float cos_alpha = sin_theta_2 / sin_theta_max + cos_theta_ * rsqrt_exact(rmax(1.0f - sin_theta_2 / sin_theta_max_2, 0.0f));
+    float sin_alpha = rsqrt_exact(rmax(1.0f - cos_alpha * cos_alpha, 0.0f));
+    float phi = u1 * 2.0f * PI_F;
+    float sphi, cphi;
+    iris_sincos(phi, sphi, cphi);
+    // vec3.rs:87-96 with (x, y, z) = (-wc_x, -wc_y, -wc)
+    V3 normal = ((sin_alpha * cphi) * (-wc_x) + (sin_alpha * sphi) * (-wc_y)) + cos_alpha * (-wc);
+    V3 sampled_point_local = radius * normalize(normal);
+    p_out = position + sampled_point_local;
+    pdf_out = pdf_cone(cos_theta_max);
+}
+IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &sphere_tests) {
+    V3 position = v3(sp.x, sp.y, sp.z);
+    float radius = sp.w;
+    V3 point = hit.back_face ? offset_origin(hit.point, -hit.normal) : offset_origin(hit.point, hit.normal);
+    if (distance_squared(position, point) <= radius * radius) {
+        Ray ray = ray_spawn(hit.point, wi, hit.normal);
+        sphere_tests++;
+        float t = sphere_hit_t(sp, ray, len_squared(ray.d));
+        if (t > 0.0f) {
+            V3 lp = ray.o + ray.d * t;
+            V3 ln = (lp - position) / radius;
+            float area = 4.0f * PI_F * (radius * radius);
+            float pdf = distance_squared(lp, point) / (dot(ln, normalize(lp - point)) * area);
+            return rmax(pdf, 0.001f);
+        }
+        return 0.0f;
+    }
+    float sin_theta_max_2 = radius * radius / distance_squared(position, hit.point);
+    float cos_theta_max = rsqrt_exact(rmax(1.0f - sin_theta_max_2, 0.0f));
+    return pdf_cone(cos_theta_max);
+}
+
+// ---------------------------------------------------------------- GGX (sampling/ggx.rs)
+IRIS_DEV V3 ggx_sample(V3 wo_in, float ax, float ay, SobolLds tab, Sampler &smp) {  // ggx.rs:7-33
+    V3 wo = normalize(v3(ax * wo_in.x, ay * wo_in.y, wo_in.z));
+    float len_2 = wo.x * wo.x + wo.y * wo.y;
+    V3 t1_v = len_2 > 0.0f ? v3(-wo.y, wo.x, 0.0f) / rsqrt_exact(len_2) : v3(1.0f, 0.0f, 0.0f);
+    V3 t2_v = cross(wo, t1_v);
+    float r = rsqrt_exact(gen_0_1(tab, smp));
+    float phi = 2.0f * PI_F * gen_0_1(tab, smp);
+    float sphi, cphi;
+    iris_sincos(phi, sphi, cphi);
+    float t1 = r * cphi;
+    float t2 = r * sphi;
+    float s = 0.5f * (1.0f + wo.z);
+    t2 = (1.0f - s) * rsqrt_exact(1.0f - t1 * t1) + s * t2;
+    V3 nh = (t1 * t1_v + t2 * t2_v) + wo * rsqrt_exact(rmax(1.0f - t1 * t1 - t2 * t2, 0.0f));
+    return normalize(v3(ax * nh.x, ay * nh.y, rmax(nh.z, 0.0f)));
+}
+IRIS_DEV float ggx_evaluate(V3 wh, float ax, float ay) {  // ggx.rs:35-43
+    float tan2 = tan_2_theta(wh);
+    if (__builtin_isinf(tan2)) return 0.0f;
+    float e = (cos_2_phi(wh) / (ax * ax) + sin_2_phi(wh) / (ay * ay)) * tan2;
+    float ct = cos_theta(wh);
+    float ct2 = ct * ct;
+    float ope = 1.0f + e;
+    return 1.0f / (PI_F * ax * ay * (ct2 * ct2) * (ope * ope));
+}
+IRIS_DEV float ggx_lambda(V3 w, float ax, float ay) {  // ggx.rs:45-55
+    float tt = tan_theta(w);
+    if (__builtin_isinf(tt)) return 0.0f;
+    float alpha = rsqrt_exact(cos_2_phi(w) * (ax * ax) + sin_2_phi(w) * (ay * ay));
+    float a = alpha * fabs_(tt);
+    return (-1.0f + rsqrt_exact(1.0f + a * a)) / 2.0f;
+}
+IRIS_DEV float ggx_g(V3 wo, V3 wh, float ax, float ay) { return 1.0f / (1.0f + ggx_lambda(wh, ax, ay) + ggx_lambda(wo, ax, ay)); }
+IRIS_DEV float ggx_g1(V3 w, float ax, float ay) { return 1.0f / (1.0f + ggx_lambda(w, ax, ay)); }
+IRIS_DEV float ggx_pdf(V3 wo, V3 wh, float ax, float ay) {  // ggx.rs:61-64
+    return ggx_evaluate(wh, ax, ay) * ggx_g1(wo, ax, ay) * fabs_(dot(wo, wh)) / fabs_(cos_theta(wo));
+}
+
+// ---------------------------------------------------------------- BSDFs (bsdf/*.rs)
+IRIS_DEV V3 reflect(V3 wo, V3 n) { return (-wo) + (2.0f * dot(wo, n)) * n; }  // microfacet.rs:91-93
+
+IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl) {  // microfacet.rs:33-57
+    float cos_theta_o = fabs_(cos_theta(wo));
+    float cos_theta_i = fabs_(cos_theta(wi));
+    V3 wh = wo + wi;
+    if (!same_hemisphere(wi, wo) || cos_theta_o == 0.0f || cos_theta_i == 0.0f || (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f))
+        return splat(0.0f);
+    wh = normalize(wh);
+    V3 wh_facing = face_forward(wh, v3(0.0f, 0.0f, 1.0f));
+    float d = ggx_evaluate(wh, b.p0, b.p1);
+    float f = fresnel_dielectric(dot(wi, wh_facing), 1.5f, 1.0f);
+    float g = ggx_g(wo, wh, b.p0, b.p1);
+    return (((spectrum_evaluate(sc.spectra[b.spec_a], wl) * d) * g) * f) / (4.0f * cos_theta_o * cos_theta_i);
+}
+IRIS_DEV F4 bsdf_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl) {
+    if (b.kind == IRIS_BSDF_LAMBERTIAN) return spectrum_evaluate(sc.spectra[b.spec_a], wl) / PI_F;  // lambertian.rs:24-31
+    if (b.kind == IRIS_BSDF_MICROFACET) return microfacet_evaluate(sc, b, wi, wo, wl);
+    return splat(0.0f);  // specular.rs:26-33, fresnel.rs:37-44
+}
+IRIS_DEV F4 bsdf_pdf(const iris_bsdf &b, V3 wi, V3 wo) {
+    if (b.kind == IRIS_BSDF_LAMBERTIAN) return splat(fabs_(cos_theta(wi)) / PI_F);  // lambertian.rs:33-35, mod.rs:56-59
+    if (b.kind == IRIS_BSDF_MICROFACET) {                                            // microfacet.rs:59-63
+        V3 wh = normalize(wi + wo);
+        return splat(ggx_pdf(wo, wh, b.p0, b.p1) / (4.0f * dot(wo, wh)));
+    }
+    return splat(0.0f);  // specular.rs:35-37, fresnel.rs:46-48
+}
+IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, SobolLds tab, Sampler &smp, V3 &wi_out, F4 &val_out, F4 &pdf_out) {
+    wi_out = v3(0.0f, 0.0f, 0.0f);
+    val_out = splat(0.0f);
+    pdf_out = splat(0.0f);
+    if (b.kind == IRIS_BSDF_LAMBERTIAN) {  // lambertian.rs:37-50
+        float r1 = gen_0_1(tab, smp);
+        float r2 = gen_0_1(tab, smp);
+        V3 wi = cosine_unit_hemisphere(r1, r2);
+        wi = same_hemisphere(wo, wi) ? wi : -wi;
+        wi_out = wi;
+        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl) / PI_F;
+        pdf_out = splat(fabs_(cos_theta(wi)) / PI_F);
+    } else if (b.kind == IRIS_BSDF_MICROFACET) {  // microfacet.rs:65-88
+        V3 wh = ggx_sample(wo, b.p0, b.p1, tab, smp);
+        V3 wi = reflect(wo, wh);
+        if (!(cos_theta(wo) == 0.0f || dot(wo, wh) < 0.0f || !same_hemisphere(wo, wi))) {
+            float pdf = ggx_pdf(wo, wh, b.p0, b.p1) / (4.0f * dot(wo, wh));
+            wi_out = wi;
+            val_out = microfacet_evaluate(sc, b, wi, wo, wl);
+            pdf_out = splat(pdf);
+        }
+    } else if (b.kind == IRIS_BSDF_SPECULAR) {  // specular.rs:39-49
+        V3 wi = v3(-wo.x, -wo.y, wo.z);
+        wi_out = wi;
+        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl) / fabs_(cos_theta(wi));
+        pdf_out = splat(1.0f);
+    } else if (b.kind == IRIS_BSDF_FRESNEL) {  // fresnel.rs:30-34, 50-102
+        const float eta_a = 1.0f;
+        F4 eta_b = b.p0 + (b.p1 / ((wl * wl) * 1e-6f));
+        F4 fr;
+#pragma unroll
+        for (int k = 0; k < 4; k++) fr.v[k] = fresnel_dielectric(cos_theta(wo), eta_a, eta_b.v[k]);
+        if (gen_0_1(tab, smp) < hero(fr)) {
+            V3 wi = v3(-wo.x, -wo.y, wo.z);
+            F4 bs = spectrum_evaluate(sc.spectra[b.spec_a], wl) / fabs_(cos_theta(wi));
+            wi_out = wi;
+            val_out = bs * fr;
+            pdf_out = fr;
+        } else {
+            float eta_i, eta_t;
+            if (cos_theta(wo) > 0.0f) { eta_i = eta_a; eta_t = hero(eta_b); }
+            else { eta_i = hero(eta_b); eta_t = eta_a; }
+            V3 wi;
+            if (refract(wo, face_forward(v3(0.0f, 0.0f, 1.0f), wo), eta_i / eta_t, wi)) {
+                F4 ft = ((spectrum_evaluate(sc.spectra[b.spec_b], wl) * (1.0f - hero(fr))) * (eta_i * eta_i)) / (eta_t * eta_t);
+                float hero_value = hero(ft) / fabs_(cos_theta(wi));
+                wi_out = wi;
+                val_out = f4(hero_value, 0.0f, 0.0f, 0.0f);
+                pdf_out = f4(1.0f - hero(fr), 0.0f, 0.0f, 0.0f);
+            }
+        }
+    }
+    // IRIS_BSDF_NULL (null.rs: unreachable!()): absorbs
+}
+
+// ---------------------------------------------------------------- path state and the two stages' per-lane work
+struct Counters { uint32_t samples, bounces, rays; unsigned long long sphere_tests; };
+
+struct PathState {
+    Ray ray;
+    float hero_nm;
+    F4 thr, ppdf, rad;
+    Sampler smp;
+    uint32_t bounce;
+};
+
+struct CamDev { float px, py, pz; float m[16]; };
+struct FrameDev { uint32_t width, height, seed, max_depth, min_depth; };
+
+// tile.rs:134-157: the camera sample for (x, y, sample_index)
+IRIS_DEV void raygen(const CamDev &cam, const FrameDev &fr, SobolLds tab, uint32_t x, uint32_t y, uint32_t sample_index, PathState &ps) {
+    float cx = (((float)x + 0.5f) / (float)fr.width - 0.5f) * 2.0f;
+    float cy = (((float)y + 0.5f) / (float)fr.height - 0.5f) * -2.0f;
+    ps.smp = sampler_new(x, y, sample_index, fr.seed);
+    ps.hero_nm = gen_golden_ratio(ps.smp) * LAMBDA_RANGE_NM + LAMBDA_MIN_NM;  // wavelength.rs:26-28
+    float j0 = 0.5f * gen_0_1(tab, ps.smp) / (float)fr.width;
+    float j1 = 0.5f * gen_0_1(tab, ps.smp) / (float)fr.height;
+    float tx = cx + j0, ty = cy + j1, tz = 0.0f + 0.0f;
+    const float *m = cam.m;  // matrix.rs:168-196
+    float w = m[12] * tx + m[13] * ty + m[14] * tz + m[15];
+    V3 target = v3((m[0] * tx + m[1] * ty + m[2] * tz + m[3]) / w,
+                   (m[4] * tx + m[5] * ty + m[6] * tz + m[7]) / w,
+                   (m[8] * tx + m[9] * ty + m[10] * tz + m[11]) / w);
+    V3 origin = v3(cam.px, cam.py, cam.pz);
+    ps.ray = ray_new(origin, target - origin);
+    ps.thr = splat(1.0f);
+    ps.ppdf = splat(1.0f);
+    ps.rad = splat(0.0f);
+    ps.bounce = 0u;
+}
+
+// What `radiance` returns for a finished path, as XYZ (tile.rs:159-162)
+template <int INTEG>
+IRIS_DEV V3 path_xyz(const PathState &ps) {
+    F4 wl = wavelength_new(ps.hero_nm);
+    F4 rad = (INTEG < 2) ? ps.rad : f4(hero(ps.rad), 0.0f, 0.0f, 0.0f);  // swss_naive.rs:87, swss_slow.rs:81
+    return spectral_to_xyz(rad, wl);
+}
+
+// One iteration of the bounce loop after a closest hit (prim, t) has been found:
+// hwss_naive.rs:46-88 + direct_light :95-157, hwss_slow.rs:46-80, swss_naive.rs:45-84 + :92-153,
+// swss_slow.rs:45-78.  Returns true while the path continues (ps.ray is then the next ray).
+// Every thread of the workgroup must call it (active=false for idle threads): the shadow scans
+// stage the sphere list cooperatively.
+template <int INTEG>
+IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, bool active,
+                           PathState &ps, int prim, float t, Counters &cnt) {
+    constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
+    constexpr bool NAIVE = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_SWSS_NAIVE);
+    bool alive = active;
+    Hit hit = {};
+    F4 wl = splat(LAMBDA_MIN_NM);
+    iris_bsdf bsdf = {IRIS_BSDF_NULL, 0u, 0u, 0.0f, 0.0f};
+    int light_index = -1;
+    if (alive) {
+        hit = sphere_frame(sc.spheres[prim], ps.ray, t);
+        wl = wavelength_new(ps.hero_nm);
+        int2 info = sc.prim_info[prim];
+        light_index = info.y;
+        if (!NAIVE && light_index >= 0) {  // hwss_slow.rs:46-49, swss_slow.rs:45-48
+            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl);
+            if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
+            else ps.rad = ps.rad + ps.thr * le;
+        }
+        if (info.x < 0) alive = false;  // no material: break
+        else bsdf = sc.bsdfs[info.x];
+    }
+    if (alive) cnt.bounces++;
+    V3 shading_wo = world_to_shading(hit, -ps.ray.d);
+
+    if (NAIVE) {
+        if (alive && ps.bounce == 0u && light_index >= 0) {  // hwss_naive.rs:51-58, swss_naive.rs:50-55
+            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl);
+            if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
+            else ps.rad = ps.rad + ps.thr * le;
+        }
+        // ---- direct_light ----
+        F4 direct = splat(0.0f);
+        F4 light_emission = splat(0.0f);
+        float4 light_sphere = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        int light_prim = -1;
+        float light_pick_weight = 0.0f;
+        // light sampling
+        Ray shadow1 = {v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f)};
+        V3 light_pos = v3(0.0f, 0.0f, 0.0f);
+        float light_pdf = 0.0f;
+        bool want1 = false;
+        if (alive) {
+            // scene.rs:168-172 + sampler.rs:52-60
+            float u = gen_0_1(tab, ps.smp);
+            uint32_t light_idx = f_as_index(u * (((float)sc.n_lights - 0.5f) - 0.0f) + 0.0f);
+            iris_light l = sc.lights[light_idx];
+            light_prim = (int)l.prim;
+            light_pick_weight = (float)sc.n_lights;
+            light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl);
+            light_sphere = sc.spheres[light_prim];
+            sphere_sample(light_sphere, hit, tab, ps.smp, light_pos, light_pdf);
+            shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
+            bool facing_forward = dot(light_pos - hit.point, hit.normal) > 0.0f;
+            want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
+        }
+        float st1;
+        int sp1;
+        scan_closest(sc, st, want1, shadow1, st1, sp1);  // scene.rs:134-149
+        if (want1) {
+            cnt.rays++;
+            cnt.sphere_tests += sc.n_prims;
+            float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
+            if (st1 > target_t - IRIS_RAY_EPSILON) {
+                V3 shading_wi = world_to_shading(hit, shadow1.d);
+                F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl);
+                F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
+                float cos_t = fabs_(cos_theta(shading_wi));
+                float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : light_pdf / (hero(bsdf_pdfs) + light_pdf);
+                direct = direct + (((mis_weight * light_emission) * bsdf_values) * cos_t) / light_pdf;
+            }
+        }
+        // BSDF sampling
+        Ray shadow2 = {v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f)};
+        bool want2 = false;
+        F4 bs_values = splat(0.0f), bs_pdfs = splat(0.0f);
+        float bs_cos = 0.0f;
+        if (alive) {
+            V3 wi;
+            bsdf_sample(sc, bsdf, shading_wo, wl, tab, ps.smp, wi, bs_values, bs_pdfs);
+            bs_cos = fabs_(cos_theta(wi));
+            shadow2 = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
+            want2 = hero(bs_pdfs) > 0.0f;
+        }
+        float st2;
+        int sp2;
+        scan_closest(sc, st, want2, shadow2, st2, sp2);  // scene.rs:151-166
+        if (want2) {
+            cnt.rays++;
+            cnt.sphere_tests += sc.n_prims;
+            if (sp2 == light_prim) {
+                float lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
+                float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : hero(bs_pdfs) / (hero(bs_pdfs) + lpdf);
+                direct = direct + (((mis_weight * light_emission) * bs_values) * bs_cos) / hero(bs_pdfs);
+            }
+        }
+        if (alive) ps.rad = ps.rad + ps.thr * (direct * light_pick_weight);  // hwss_naive.rs:61-62, :155
+    }
+
+    if (alive) {
+        // hwss_naive.rs:64-88
+        V3 wi;
+        F4 bsdf_values, bsdf_pdfs;
+        bsdf_sample(sc, bsdf, shading_wo, wl, tab, ps.smp, wi, bsdf_values, bsdf_pdfs);
+        float cos_t = fabs_(cos_theta(wi));
+        if (hero(bsdf_pdfs) == 0.0f || cos_t == 0.0f) {
+            alive = false;
+        } else {
+            ps.thr = ps.thr * ((bsdf_values * cos_t) / hero(bsdf_pdfs));
+            if (HWSS) ps.ppdf = ps.ppdf * bsdf_pdfs;
+            if (ps.bounce >= fr.min_depth) {
+                float p = rmin(sum(ps.thr), 0.95f);
+                if (gen_0_1(tab, ps.smp) > p) alive = false;
+                else ps.thr = ps.thr / splat(p);
+            }
+            if (alive) {
+                ps.ray = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
+                ps.bounce += 1u;
+                if (ps.bounce >= fr.max_depth) alive = false;  // for bounces in 0..MAX_DEPTH
+            }
+        }
+    }
+    return alive;
+}
+
+}  // namespace iris

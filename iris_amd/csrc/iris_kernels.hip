@@ -1,0 +1,902 @@
+// iris_kernels.hip -- wavefront path-tracing kernels for gfx950 and the C ABI of libiris_hip.so.
+//
+// Layout of the work (DESIGN.md has the long version):
+//   * A render is a list of items (sample index, pixel), sample-major.  Every persistent workgroup
+//     owns a contiguous range of items, a private pool of path-state slots (SoA arrays in HBM, sized to
+//     stay L2 / Infinity-Cache resident) and a private queue, so workgroups never talk to each other and
+//     the result does not depend on scheduling.
+//   * Stage A (generate + extend): every slot whose path is dead is refilled with the next item of the
+//     workgroup's range (wave64 ballot + prefix sum, one LDS atomic per wave), the camera ray is generated,
+//     and every live ray is intersected with the sphere list staged in LDS.  Misses are finished (their
+//     XYZ goes to the per-sample result buffer), hits are compacted into the shade queue (ballot + prefix
+//     sum again).
+//   * Stage B (shade): one lane per queue entry: emission, next-event estimation with both MIS
+//     strategies (two shadow scans), BSDF sampling, Russian roulette, next ray.
+//   * Resolve: per pixel, the per-sample XYZ values are summed in ascending sample order (the order of
+//     tile.rs:144-163) and scaled by 1/spp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "iris_device.h"
+
+#define IRIS_SOBOL_TABLE_QUAL __device__ const
+#undef IRIS_TABLE_QUAL
+#define IRIS_TABLE_QUAL __device__ const
+#include "tables/sobol_rev16.inc"
+
+using namespace iris;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr uint32_t STATE_ALIVE = 0x80000000u;
+
+struct Pool {
+    float4 *rayo;  // (ox, oy, oz, hero wavelength)
+    float4 *rayd;  // (dx, dy, dz, state bits: alive << 31 | bounce)
+    float4 *thr;   // throughput, 4 wavelengths
+    float4 *ppdf;  // path pdfs, 4 wavelengths
+    float4 *rad;   // radiance, 4 wavelengths
+    uint4 *smp;    // sampler: q0, q1, q2 (f32 bits), dimension | in_buffer << 16
+    uint4 *meta;   // scramble, sample index, item id, unused
+    uint2 *hit;    // closest hit of stage A: primitive, t (f32 bits)
+};
+
+struct WfArgs {
+    SceneDev sc;
+    CamDev cam;
+    FrameDev fr;
+    Pool pool;
+    float4 *results;          // per item: XYZ of the finished path
+    uint32_t *queue;          // per workgroup: slots_per_block entries
+    uint32_t *blk_cursor;     // per workgroup: next item (multi-kernel mode)
+    uint32_t *blk_qn;         // per workgroup: queue length (multi-kernel mode)
+    uint32_t *live_blocks;    // multi-kernel mode: workgroups that still have work after stage A
+    unsigned long long *counters;  // samples, bounces, rays, sphere_tests
+    uint32_t npix;
+    uint32_t s_begin;         // sample index of item 0 of this chunk
+    uint32_t n_items;         // items in this chunk
+    uint32_t items_per_block;
+    uint32_t slots_per_block;
+    uint32_t sphere_cap;      // LDS window, in spheres
+};
+
+struct BlockShared {
+    uint32_t cursor, w_end, qn;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// exclusive prefix count of `mask` below this lane
+__device__ __forceinline__ uint32_t prefix_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// Reserve `popcount(ballot(pred))` consecutive entries of an LDS counter for the wave; returns this lane's index.
+__device__ __forceinline__ uint32_t wave_reserve(bool pred, uint32_t *lds_counter) {
+    unsigned long long mask = __ballot(pred);
+    uint32_t count = (uint32_t)__popcll(mask);
+    uint32_t base = 0u;
+    if (count != 0u && lane_id() == 0u) base = atomicAdd(lds_counter, count);
+    base = __builtin_amdgcn_readfirstlane(base);
+    return base + prefix_below(mask);
+}
+
+__device__ __forceinline__ void stage_tables(uint2 *sobol_lds) {
+    for (uint32_t e = threadIdx.x; e < 16u * IRIS_SOBOL_SETS; e += blockDim.x) {
+        uint32_t b = e / IRIS_SOBOL_SETS, set = e % IRIS_SOBOL_SETS;
+        const unsigned short *v = IRIS_SOBOL_REV16[set][b];
+        sobol_lds[e] = make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
+    }
+}
+__device__ __forceinline__ SphereStage stage_spheres(const SceneDev &sc, float4 *win, uint32_t cap) {
+    SphereStage st;
+    st.lds = win;
+    st.cap = cap;
+    st.resident = sc.n_prims <= cap;
+    if (st.resident)
+        for (uint32_t i = threadIdx.x; i < sc.n_prims; i += blockDim.x) win[i] = sc.spheres[i];
+    return st;
+}
+
+__device__ __forceinline__ void store_result(const WfArgs &a, uint32_t item, V3 xyz) {
+    a.results[item] = make_float4(xyz.x, xyz.y, xyz.z, 0.0f);
+}
+
+__device__ __forceinline__ void flush_counters(const WfArgs &a, const Counters &c) {
+    // wave reduction, then one atomic per wave and counter
+    unsigned long long v[4] = {c.samples, c.bounces, c.rays, c.sphere_tests};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane_id() == 0u && x) atomicAdd(&a.counters[k], x);
+    }
+}
+
+// ---- stage A: refill dead slots, generate camera rays, closest hit, compact hits into the queue ----
+template <int INTEG>
+__device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereStage &st, SobolLds tab, BlockShared &bs, Counters &cnt) {
+    const uint32_t slot0 = blockIdx.x * a.slots_per_block;
+    for (uint32_t tile = 0; tile < a.slots_per_block; tile += BLOCK) {
+        const uint32_t slot = slot0 + tile + threadIdx.x;
+        float4 rd = a.pool.rayd[slot];
+        const bool was_alive = (__float_as_uint(rd.w) & STATE_ALIVE) != 0u;
+        // refill: dead lanes take the next items of this workgroup's range
+        const uint32_t id = wave_reserve(!was_alive, &bs.cursor);
+        const bool regen = !was_alive && id < bs.w_end;
+        PathState ps;
+        uint32_t item = 0u;
+        if (regen) {
+            item = id;
+            uint32_t s_local = id / a.npix;
+            uint32_t pix = id - s_local * a.npix;
+            uint32_t y = pix / a.fr.width;
+            uint32_t x = pix - y * a.fr.width;
+            raygen(a.cam, a.fr, tab, x, y, a.s_begin + s_local, ps);
+            cnt.samples++;
+        } else if (was_alive) {
+            float4 ro = a.pool.rayo[slot];
+            ps.ray.o = v3(ro.x, ro.y, ro.z);
+            ps.ray.d = v3(rd.x, rd.y, rd.z);
+            ps.hero_nm = ro.w;
+        } else {
+            ps.ray.o = v3(0.0f, 0.0f, 0.0f);
+            ps.ray.d = v3(0.0f, 0.0f, 1.0f);
+        }
+        const bool active = regen || was_alive;
+        float t;
+        int prim;
+        scan_closest(a.sc, st, active, ps.ray, t, prim);
+        if (active) { cnt.rays++; cnt.sphere_tests += a.sc.n_prims; }
+        const bool hitp = active && prim >= 0;
+        if (active && !hitp) {  // the path left the scene: `None => break` (hwss_naive.rs:41-44)
+            if (regen) {
+                store_result(a, item, v3(0.0f, 0.0f, 0.0f));  // radiance is still exactly zero
+            } else {
+                float4 r = a.pool.rad[slot];
+                ps.rad = f4(r.x, r.y, r.z, r.w);
+                store_result(a, a.pool.meta[slot].z, path_xyz<INTEG>(ps));
+                rd.w = __uint_as_float(0u);
+                a.pool.rayd[slot] = rd;
+            }
+        }
+        const uint32_t qi = wave_reserve(hitp, &bs.qn);
+        if (hitp) {
+            if (regen) {
+                a.pool.rayo[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.hero_nm);
+                a.pool.rayd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(STATE_ALIVE));
+                a.pool.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                if (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW) a.pool.ppdf[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                a.pool.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                a.pool.smp[slot] = make_uint4(__float_as_uint(ps.smp.q0), __float_as_uint(ps.smp.q1), __float_as_uint(ps.smp.q2),
+                                              ps.smp.dimension | (ps.smp.in_buffer << 16));
+                a.pool.meta[slot] = make_uint4(ps.smp.scramble, ps.smp.index, item, 0u);
+            }
+            a.pool.hit[slot] = make_uint2((uint32_t)prim, __float_as_uint(t));
+            a.queue[slot0 + qi] = slot;
+        }
+    }
+}
+
+// ---- stage B: shade every queued hit ----
+template <int INTEG>
+__device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &st, SobolLds tab, uint32_t qn, Counters &cnt) {
+    constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
+    const uint32_t slot0 = blockIdx.x * a.slots_per_block;
+    for (uint32_t base = 0; base < qn; base += BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < qn;
+        PathState ps;
+        uint32_t slot = slot0, item = 0u;
+        int prim = 0;
+        float t = 0.0f;
+        if (active) {
+            slot = a.queue[slot0 + i];
+            float4 ro = a.pool.rayo[slot], rd = a.pool.rayd[slot], th = a.pool.thr[slot], ra = a.pool.rad[slot];
+            uint4 sm = a.pool.smp[slot], me = a.pool.meta[slot];
+            uint2 h = a.pool.hit[slot];
+            ps.ray.o = v3(ro.x, ro.y, ro.z);
+            ps.ray.d = v3(rd.x, rd.y, rd.z);
+            ps.hero_nm = ro.w;
+            ps.bounce = __float_as_uint(rd.w) & 0xffffu;
+            ps.thr = f4(th.x, th.y, th.z, th.w);
+            if (HWSS) { float4 pp = a.pool.ppdf[slot]; ps.ppdf = f4(pp.x, pp.y, pp.z, pp.w); }
+            else ps.ppdf = splat(1.0f);
+            ps.rad = f4(ra.x, ra.y, ra.z, ra.w);
+            ps.smp.q0 = __uint_as_float(sm.x); ps.smp.q1 = __uint_as_float(sm.y); ps.smp.q2 = __uint_as_float(sm.z);
+            ps.smp.dimension = sm.w & 0xffffu; ps.smp.in_buffer = sm.w >> 16;
+            ps.smp.scramble = me.x; ps.smp.index = me.y; ps.smp.draws = 0u;
+            item = me.z;
+            prim = (int)h.x;
+            t = __uint_as_float(h.y);
+        } else {
+            ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
+            ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
+            ps.smp = sampler_new(0u, 0u, 0u, 0u);
+        }
+        const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, tab, active, ps, prim, t, cnt);
+        if (active) {
+            if (cont) {
+                a.pool.rayo[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.hero_nm);
+                a.pool.rayd[slot] = make_float4(ps.ray.d.x, ps.ray.d.y, ps.ray.d.z, __uint_as_float(STATE_ALIVE | ps.bounce));
+                a.pool.thr[slot] = make_float4(ps.thr.v[0], ps.thr.v[1], ps.thr.v[2], ps.thr.v[3]);
+                if (HWSS) a.pool.ppdf[slot] = make_float4(ps.ppdf.v[0], ps.ppdf.v[1], ps.ppdf.v[2], ps.ppdf.v[3]);
+                a.pool.rad[slot] = make_float4(ps.rad.v[0], ps.rad.v[1], ps.rad.v[2], ps.rad.v[3]);
+                a.pool.smp[slot] = make_uint4(__float_as_uint(ps.smp.q0), __float_as_uint(ps.smp.q1), __float_as_uint(ps.smp.q2),
+                                              ps.smp.dimension | (ps.smp.in_buffer << 16));
+            } else {
+                store_result(a, item, path_xyz<INTEG>(ps));
+                a.pool.rayd[slot] = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(0u));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void block_range(const WfArgs &a, uint32_t &begin, uint32_t &end) {
+    unsigned long long b = (unsigned long long)blockIdx.x * a.items_per_block;
+    unsigned long long e = b + a.items_per_block;
+    if (b > a.n_items) b = a.n_items;
+    if (e > a.n_items) e = a.n_items;
+    begin = (uint32_t)b;
+    end = (uint32_t)e;
+}
+
+// ---- the persistent kernel: both stages in a loop, one workgroup = one independent wavefront tracer ----
+template <int INTEG>
+__global__ void __launch_bounds__(BLOCK) k_wavefront(WfArgs a) {
+    extern __shared__ float4 sphere_win[];
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ BlockShared bs;
+    stage_tables(sobol_lds);
+    SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
+    if (threadIdx.x == 0) {
+        block_range(a, bs.cursor, bs.w_end);
+        bs.qn = 0u;
+    }
+    const uint32_t slot0 = blockIdx.x * a.slots_per_block;
+    for (uint32_t s = threadIdx.x; s < a.slots_per_block; s += BLOCK) a.pool.rayd[slot0 + s] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    __syncthreads();
+    Counters cnt = {0u, 0u, 0u, 0u};
+    for (;;) {
+        stage_gen_extend<INTEG>(a, st, sobol_lds, bs, cnt);
+        __syncthreads();
+        const uint32_t qn = bs.qn;
+        const bool more = bs.cursor < bs.w_end;
+        if (qn == 0u && !more) break;
+        stage_shade<INTEG>(a, st, sobol_lds, qn, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0) bs.qn = 0u;
+        __syncthreads();
+    }
+    flush_counters(a, cnt);
+}
+
+// ---- the same two stages as separate kernels (profiling / north-star layout) ----
+__global__ void __launch_bounds__(BLOCK) k_pool_init(WfArgs a) {
+    const uint32_t slot0 = blockIdx.x * a.slots_per_block;
+    for (uint32_t s = threadIdx.x; s < a.slots_per_block; s += BLOCK) a.pool.rayd[slot0 + s] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+    if (threadIdx.x == 0) {
+        uint32_t b, e;
+        block_range(a, b, e);
+        a.blk_cursor[blockIdx.x] = b;
+        a.blk_qn[blockIdx.x] = 0u;
+    }
+}
+template <int INTEG>
+__global__ void __launch_bounds__(BLOCK) k_stage_gen_extend(WfArgs a) {
+    extern __shared__ float4 sphere_win[];
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ BlockShared bs;
+    stage_tables(sobol_lds);
+    SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
+    if (threadIdx.x == 0) {
+        uint32_t b;
+        block_range(a, b, bs.w_end);
+        bs.cursor = a.blk_cursor[blockIdx.x];
+        bs.qn = 0u;
+    }
+    __syncthreads();
+    Counters cnt = {0u, 0u, 0u, 0u};
+    stage_gen_extend<INTEG>(a, st, sobol_lds, bs, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.blk_cursor[blockIdx.x] = bs.cursor < bs.w_end ? bs.cursor : bs.w_end;
+        a.blk_qn[blockIdx.x] = bs.qn;
+        if (bs.qn != 0u || bs.cursor < bs.w_end) atomicAdd(a.live_blocks, 1u);
+    }
+    flush_counters(a, cnt);
+}
+template <int INTEG>
+__global__ void __launch_bounds__(BLOCK) k_stage_shade(WfArgs a) {
+    extern __shared__ float4 sphere_win[];
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    const uint32_t qn = a.blk_qn[blockIdx.x];
+    if (qn == 0u) return;
+    stage_tables(sobol_lds);
+    SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
+    __syncthreads();
+    Counters cnt = {0u, 0u, 0u, 0u};
+    stage_shade<INTEG>(a, st, sobol_lds, qn, cnt);
+    flush_counters(a, cnt);
+}
+
+// ---- film resolve: ordered per-pixel sum of the per-sample results ----
+__global__ void __launch_bounds__(BLOCK) k_resolve(const float4 *__restrict__ results, float4 *__restrict__ film_acc, float *__restrict__ out,
+                                                   uint32_t npix, uint32_t n_samples, int first, int last, float weight) {
+    uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
+    if (pix >= npix) return;
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    if (!first) { float4 acc = film_acc[pix]; x = acc.x; y = acc.y; z = acc.z; }
+    for (uint32_t s = 0; s < n_samples; s++) {  // tile.rs:159: xyz_sum += ..., ascending sample index
+        float4 r = results[(size_t)s * npix + pix];
+        x += r.x; y += r.y; z += r.z;
+    }
+    if (last) {  // tile.rs:165: xyz_sum * weight
+        out[3 * (size_t)pix + 0] = x * weight;
+        out[3 * (size_t)pix + 1] = y * weight;
+        out[3 * (size_t)pix + 2] = z * weight;
+    } else {
+        film_acc[pix] = make_float4(x, y, z, 0.0f);
+    }
+}
+
+// ---- stage-level debug kernels (parity tests) ----
+__global__ void __launch_bounds__(BLOCK) k_dbg_sampler(const uint32_t *xys, uint32_t n, uint32_t seed, uint32_t ndraws, float *out) {
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    stage_tables(sobol_lds);
+    __syncthreads();
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Sampler s = sampler_new(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], seed);
+    for (uint32_t k = 0; k < ndraws; k++) out[(size_t)i * ndraws + k] = gen_0_1(sobol_lds, s);
+}
+__global__ void __launch_bounds__(BLOCK) k_dbg_raygen(CamDev cam, FrameDev fr, const uint32_t *xys, uint32_t n, float *hero_out, float *o_out, float *d_out) {
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    stage_tables(sobol_lds);
+    __syncthreads();
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    PathState ps;
+    raygen(cam, fr, sobol_lds, xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], ps);
+    F4 wl = wavelength_new(ps.hero_nm);
+    for (int k = 0; k < 4; k++) hero_out[4 * i + k] = wl.v[k];
+    o_out[3 * i] = ps.ray.o.x; o_out[3 * i + 1] = ps.ray.o.y; o_out[3 * i + 2] = ps.ray.o.z;
+    d_out[3 * i] = ps.ray.d.x; d_out[3 * i + 1] = ps.ray.d.y; d_out[3 * i + 2] = ps.ray.d.z;
+}
+__global__ void __launch_bounds__(BLOCK) k_dbg_intersect(SceneDev sc, uint32_t cap, const float *o, const float *d, uint32_t n, int32_t *prim_out, float *t_out) {
+    extern __shared__ float4 sphere_win[];
+    SphereStage st = stage_spheres(sc, sphere_win, cap);
+    __syncthreads();
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    bool active = i < n;
+    Ray ray = {v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f)};
+    if (active) { ray.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); ray.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]); }
+    float t;
+    int prim;
+    scan_closest(sc, st, active, ray, t, prim);
+    if (active) { prim_out[i] = prim; t_out[i] = t; }
+}
+template <int INTEG>
+__global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, FrameDev fr, uint32_t cap, const uint32_t *xys, uint32_t n, iris_trace *out) {
+    extern __shared__ float4 sphere_win[];
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    stage_tables(sobol_lds);
+    SphereStage st = stage_spheres(sc, sphere_win, cap);
+    __syncthreads();
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    bool alive = i < n;
+    PathState ps;
+    Counters cnt = {0u, 0u, 0u, 0u};
+    iris_trace *tr = alive ? &out[i] : nullptr;
+    if (alive) {
+        raygen(cam, fr, sobol_lds, xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], ps);
+        F4 wl = wavelength_new(ps.hero_nm);
+        for (int k = 0; k < 4; k++) tr->hero[k] = wl.v[k];
+        tr->ray_o[0] = ps.ray.o.x; tr->ray_o[1] = ps.ray.o.y; tr->ray_o[2] = ps.ray.o.z;
+        tr->ray_d[0] = ps.ray.d.x; tr->ray_d[1] = ps.ray.d.y; tr->ray_d[2] = ps.ray.d.z;
+        tr->n_hits = 0u;
+    } else {
+        ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
+        ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
+        ps.smp = sampler_new(0u, 0u, 0u, 0u);
+    }
+    uint32_t n_hits = 0u;
+    while (__syncthreads_or(alive ? 1 : 0)) {
+        float t;
+        int prim;
+        scan_closest(sc, st, alive, ps.ray, t, prim);
+        if (alive && prim < 0) alive = false;
+        if (alive) {
+            if (n_hits < IRIS_TRACE_MAX_DEPTH) { tr->hit_prim[n_hits] = prim; tr->hit_t[n_hits] = t; }
+            n_hits++;
+        }
+        alive = shade_bounce<INTEG>(sc, st, fr, sobol_lds, alive, ps, prim, t, cnt);
+    }
+    if (tr) {
+        V3 xyz = path_xyz<INTEG>(ps);
+        F4 rad = (INTEG < 2) ? ps.rad : f4(hero(ps.rad), 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < 4; k++) tr->radiance[k] = rad.v[k];
+        tr->xyz[0] = xyz.x; tr->xyz[1] = xyz.y; tr->xyz[2] = xyz.z;
+        tr->n_hits = n_hits < IRIS_TRACE_MAX_DEPTH ? n_hits : IRIS_TRACE_MAX_DEPTH;
+        tr->draws = ps.smp.draws;
+    }
+}
+
+}  // namespace
+
+// =====================================================================================================
+// Host side: the C ABI
+// =====================================================================================================
+
+struct iris_ctx {
+    int device = 0;
+    int n_cus = 0;
+    std::string err;
+    // options
+    int64_t blocks_per_cu = 4;
+    int64_t slots_per_block = 1024;
+    int64_t result_bytes = 64ll << 30;
+    int64_t multi_kernel = 0;
+    // scene
+    bool have_scene = false;
+    SceneDev sc = {};
+    void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr;
+    // pools
+    uint32_t pool_blocks = 0, pool_slots_per_block = 0;
+    Pool pool = {};
+    uint32_t *d_queue = nullptr, *d_blk_cursor = nullptr, *d_blk_qn = nullptr, *d_live = nullptr;
+    unsigned long long *d_counters = nullptr;
+    float4 *d_results = nullptr;
+    size_t results_cap = 0;  // items
+    float4 *d_film_acc = nullptr;
+    size_t film_cap = 0;
+    uint32_t *h_live = nullptr;  // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    iris_stats stats = {};
+};
+
+namespace {
+
+constexpr uint32_t SPHERE_CAP = 2048;  // LDS window: 32 KiB of float4
+
+int fail(iris_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                                     \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) return fail(ctx, IRIS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(iris_ctx *ctx, T **p, size_t n) {
+    HIP_TRY(ctx, hipMalloc((void **)p, n * sizeof(T)));
+    return IRIS_OK;
+}
+void dev_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+void free_pools(iris_ctx *c) {
+    dev_free(c->pool.rayo); dev_free(c->pool.rayd); dev_free(c->pool.thr); dev_free(c->pool.ppdf); dev_free(c->pool.rad);
+    dev_free(c->pool.smp); dev_free(c->pool.meta); dev_free(c->pool.hit);
+    dev_free(c->d_queue); dev_free(c->d_blk_cursor); dev_free(c->d_blk_qn);
+    c->pool = Pool{};
+    c->d_queue = c->d_blk_cursor = c->d_blk_qn = nullptr;
+    c->pool_blocks = c->pool_slots_per_block = 0;
+}
+
+int ensure_pools(iris_ctx *c, uint32_t blocks, uint32_t spb) {
+    if (c->pool_blocks == blocks && c->pool_slots_per_block == spb) return IRIS_OK;
+    free_pools(c);
+    size_t n = (size_t)blocks * spb;
+    int rc;
+    if ((rc = dev_alloc(c, &c->pool.rayo, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pool.rayd, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pool.thr, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pool.ppdf, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pool.rad, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pool.smp, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pool.meta, n))) return rc;
+    if ((rc = dev_alloc(c, &c->pool.hit, n))) return rc;
+    if ((rc = dev_alloc(c, &c->d_queue, n))) return rc;
+    if ((rc = dev_alloc(c, &c->d_blk_cursor, (size_t)blocks))) return rc;
+    if ((rc = dev_alloc(c, &c->d_blk_qn, (size_t)blocks))) return rc;
+    c->pool_blocks = blocks;
+    c->pool_slots_per_block = spb;
+    return IRIS_OK;
+}
+
+CamDev cam_dev(const iris_camera *cam) {
+    CamDev c;
+    c.px = cam->position[0]; c.py = cam->position[1]; c.pz = cam->position[2];
+    std::memcpy(c.m, cam->clip_to_world, sizeof c.m);
+    return c;
+}
+
+int check_params(iris_ctx *ctx, const iris_render_params *p) {
+    if (!p) return fail(ctx, IRIS_E_ARG, "params is NULL");
+    if (p->width == 0 || p->height == 0) return fail(ctx, IRIS_E_ARG, "width and height must be positive");
+    if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(ctx, IRIS_E_LIMIT, "more than 2^31 pixels");
+    if (p->spp_total == 0) return fail(ctx, IRIS_E_ARG, "spp_total must be positive");
+    if (p->integrator > IRIS_INT_SWSS_SLOW) return fail(ctx, IRIS_E_ARG, "unknown integrator");
+    if (p->max_depth > 0xffffu) return fail(ctx, IRIS_E_LIMIT, "max_depth above 65535");
+    if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(ctx, IRIS_E_ARG, "sample index overflows u32");
+    return IRIS_OK;
+}
+int check_scene_for(iris_ctx *ctx, const iris_render_params *p) {
+    if (!ctx->have_scene) return fail(ctx, IRIS_E_STATE, "no scene uploaded");
+    bool naive = p->integrator == IRIS_INT_HWSS_NAIVE || p->integrator == IRIS_INT_SWSS_NAIVE;
+    // pick_one_light on an empty light list indexes out of bounds in the reference (scene.rs:168-172)
+    if (naive && ctx->sc.n_lights == 0) return fail(ctx, IRIS_E_ARG, "next-event estimation needs at least one light");
+    return IRIS_OK;
+}
+FrameDev frame_dev(const iris_render_params *p) {
+    FrameDev f = {p->width, p->height, p->seed, p->max_depth, p->min_depth};
+    return f;
+}
+uint32_t sphere_cap_for(const iris_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->sc.n_prims, 1u), SPHERE_CAP); }
+
+template <int INTEG>
+int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stream) {
+    size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
+    if (!c->multi_kernel) {
+        hipLaunchKernelGGL(k_wavefront<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        HIP_TRY(c, hipGetLastError());
+        c->stats.launches += 1;
+        return IRIS_OK;
+    }
+    hipLaunchKernelGGL(k_pool_init, dim3(blocks), dim3(BLOCK), 0, stream, a);
+    HIP_TRY(c, hipGetLastError());
+    // Launch stage pairs in batches; after each batch read back how many workgroups still had work.
+    const int BATCH = 8;
+    for (;;) {
+        for (int it = 0; it < BATCH; it++) {
+            HIP_TRY(c, hipMemsetAsync(c->d_live, 0, sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(k_stage_gen_extend<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+            hipLaunchKernelGGL(k_stage_shade<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+            c->stats.launches += 2;
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(c->h_live, c->d_live, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        if (*c->h_live == 0u) break;
+    }
+    return IRIS_OK;
+}
+
+int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *d_out, hipStream_t stream) {
+    int rc;
+    if ((rc = check_params(c, p))) return rc;
+    if ((rc = check_scene_for(c, p))) return rc;
+    if (!cam || !d_out) return fail(c, IRIS_E_ARG, "camera or output is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t npix = p->width * p->height;
+    c->stats = iris_stats{};
+    // chunking of the sample range so that the per-sample result buffer fits its budget
+    uint64_t max_items = std::min<uint64_t>((uint64_t)c->result_bytes / sizeof(float4), 1ull << 31);
+    if (max_items < npix) return fail(c, IRIS_E_LIMIT, "result_bytes is smaller than one sample of the film");
+    uint32_t spp_per_chunk = (uint32_t)std::min<uint64_t>(max_items / npix, std::max<uint32_t>(p->spp_count, 1u));
+    size_t need_items = (size_t)spp_per_chunk * npix;
+    if (c->results_cap < need_items) {
+        dev_free(c->d_results);
+        c->d_results = nullptr;
+        c->results_cap = 0;
+        if ((rc = dev_alloc(c, &c->d_results, need_items))) return rc;
+        c->results_cap = need_items;
+    }
+    if (c->film_cap < npix) {
+        dev_free(c->d_film_acc);
+        c->d_film_acc = nullptr;
+        c->film_cap = 0;
+        if ((rc = dev_alloc(c, &c->d_film_acc, (size_t)npix))) return rc;
+        c->film_cap = npix;
+    }
+    uint32_t blocks = (uint32_t)(c->n_cus * c->blocks_per_cu);
+    uint32_t spb = (uint32_t)c->slots_per_block;
+    if ((rc = ensure_pools(c, blocks, spb))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+
+    const float weight = 1.0f / (float)p->spp_total;  // tile.rs:140
+    if (p->spp_count == 0 || p->max_depth == 0) {  // `for bounces in 0..0` never runs: radiance is zero
+        HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)npix * 3 * sizeof(float), stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        return IRIS_OK;
+    }
+    float trace_ms = 0.0f, resolve_ms = 0.0f;
+    for (uint32_t done = 0; done < p->spp_count; done += spp_per_chunk) {
+        uint32_t n_s = std::min(spp_per_chunk, p->spp_count - done);
+        WfArgs a;
+        a.sc = c->sc;
+        a.cam = cam_dev(cam);
+        a.fr = frame_dev(p);
+        a.pool = c->pool;
+        a.results = c->d_results;
+        a.queue = c->d_queue;
+        a.blk_cursor = c->d_blk_cursor;
+        a.blk_qn = c->d_blk_qn;
+        a.live_blocks = c->d_live;
+        a.counters = c->d_counters;
+        a.npix = npix;
+        a.s_begin = p->spp_begin + done;
+        a.n_items = n_s * npix;
+        a.items_per_block = (a.n_items + blocks - 1) / blocks;
+        a.slots_per_block = spb;
+        a.sphere_cap = sphere_cap_for(c);
+        HIP_TRY(c, hipEventRecord(c->ev0, stream));
+        switch (p->integrator) {
+        case IRIS_INT_HWSS_NAIVE: rc = launch_chunk<IRIS_INT_HWSS_NAIVE>(c, a, blocks, stream); break;
+        case IRIS_INT_HWSS_SLOW: rc = launch_chunk<IRIS_INT_HWSS_SLOW>(c, a, blocks, stream); break;
+        case IRIS_INT_SWSS_NAIVE: rc = launch_chunk<IRIS_INT_SWSS_NAIVE>(c, a, blocks, stream); break;
+        default: rc = launch_chunk<IRIS_INT_SWSS_SLOW>(c, a, blocks, stream); break;
+        }
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev1, stream));
+        bool first = done == 0, last = done + n_s >= p->spp_count;
+        hipLaunchKernelGGL(k_resolve, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, c->d_results, c->d_film_acc, d_out, npix, n_s,
+                           first ? 1 : 0, last ? 1 : 0, weight);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev2, stream));
+        HIP_TRY(c, hipEventSynchronize(c->ev2));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        trace_ms += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev1, c->ev2));
+        resolve_ms += ms;
+        c->stats.chunks += 1;
+    }
+    unsigned long long h[4];
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    c->stats.samples = h[0];
+    c->stats.bounces = h[1];
+    c->stats.rays = h[2];
+    c->stats.sphere_tests = h[3];
+    c->stats.kernel_ms = trace_ms;
+    c->stats.resolve_ms = resolve_ms;
+    return IRIS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iris_ctx_create(int device, iris_ctx **out) {
+    if (!out) return IRIS_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return IRIS_E_HIP;
+    iris_ctx *c = new (std::nothrow) iris_ctx();
+    if (!c) return IRIS_E_HIP;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
+    c->n_cus = prop.multiProcessorCount;
+    if (hipMalloc((void **)&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
+        iris_ctx_destroy(c);
+        return IRIS_E_HIP;
+    }
+    *out = c;
+    return IRIS_OK;
+}
+
+void iris_ctx_destroy(iris_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_pools(c);
+    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
+    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc);
+    if (c->h_live) (void)hipHostFree(c->h_live);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    delete c;
+}
+
+const char *iris_last_error(const iris_ctx *ctx) { return ctx ? ctx->err.c_str() : "invalid context"; }
+
+int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return IRIS_E_ARG;
+    std::string k(key);
+    if (k == "blocks_per_cu") {
+        if (value < 1 || value > 64) return fail(c, IRIS_E_ARG, "blocks_per_cu out of range [1, 64]");
+        c->blocks_per_cu = value;
+    } else if (k == "slots_per_block") {
+        if (value < BLOCK || value > 65536 || value % BLOCK) return fail(c, IRIS_E_ARG, "slots_per_block must be a multiple of 256 in [256, 65536]");
+        c->slots_per_block = value;
+    } else if (k == "result_bytes") {
+        if (value < (1 << 20)) return fail(c, IRIS_E_ARG, "result_bytes below 1 MiB");
+        c->result_bytes = value;
+    } else if (k == "multi_kernel") {
+        c->multi_kernel = value ? 1 : 0;
+    } else {
+        return fail(c, IRIS_E_ARG, "unknown option " + k);
+    }
+    return IRIS_OK;
+}
+
+int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
+    if (!c) return IRIS_E_ARG;
+    if (!s) return fail(c, IRIS_E_ARG, "scene is NULL");
+    if (s->n_prims == 0 || !s->spheres || !s->prim_material || !s->prim_light) return fail(c, IRIS_E_ARG, "scene has no primitives");
+    if ((s->n_bsdfs && !s->bsdfs) || (s->n_spectra && !s->spectra) || (s->n_lights && !s->lights)) return fail(c, IRIS_E_ARG, "NULL table with non-zero count");
+    // validate every index the kernels will follow, so that a malformed scene cannot fault the GPU
+    for (uint32_t i = 0; i < s->n_prims; i++) {
+        if (s->prim_material[i] < -1 || s->prim_material[i] >= (int32_t)s->n_bsdfs) return fail(c, IRIS_E_ARG, "prim_material out of range");
+        if (s->prim_light[i] < -1 || s->prim_light[i] >= (int32_t)s->n_lights) return fail(c, IRIS_E_ARG, "prim_light out of range");
+    }
+    for (uint32_t i = 0; i < s->n_bsdfs; i++) {
+        const iris_bsdf &b = s->bsdfs[i];
+        if (b.kind > IRIS_BSDF_NULL) return fail(c, IRIS_E_ARG, "unknown bsdf kind");
+        if (b.kind != IRIS_BSDF_NULL && b.spec_a >= s->n_spectra) return fail(c, IRIS_E_ARG, "bsdf spec_a out of range");
+        if (b.kind == IRIS_BSDF_FRESNEL && b.spec_b >= s->n_spectra) return fail(c, IRIS_E_ARG, "bsdf spec_b out of range");
+        if (b.kind == IRIS_BSDF_MICROFACET && (b.p0 == 0.0f || b.p1 == 0.0f)) return fail(c, IRIS_E_ARG, "microfacet alpha must be non-zero");
+    }
+    for (uint32_t i = 0; i < s->n_spectra; i++)
+        if (s->spectra[i].kind > IRIS_SPEC_UPSAMPLED_HDR) return fail(c, IRIS_E_ARG, "unknown spectrum kind");
+    for (uint32_t i = 0; i < s->n_lights; i++) {
+        if (s->lights[i].spectrum >= s->n_spectra) return fail(c, IRIS_E_ARG, "light spectrum out of range");
+        if (s->lights[i].prim >= s->n_prims) return fail(c, IRIS_E_ARG, "light prim out of range");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
+    c->d_spheres = c->d_prim_info = c->d_bsdfs = c->d_spectra = c->d_lights = nullptr;
+    c->have_scene = false;
+    std::vector<int2> info(s->n_prims);
+    for (uint32_t i = 0; i < s->n_prims; i++) info[i] = make_int2(s->prim_material[i], s->prim_light[i]);
+    auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    HIP_TRY(c, up(&c->d_spheres, s->spheres, sizeof(iris_sphere) * s->n_prims));
+    HIP_TRY(c, up(&c->d_prim_info, info.data(), sizeof(int2) * s->n_prims));
+    HIP_TRY(c, up(&c->d_bsdfs, s->bsdfs, sizeof(iris_bsdf) * s->n_bsdfs));
+    HIP_TRY(c, up(&c->d_spectra, s->spectra, sizeof(iris_spectrum) * s->n_spectra));
+    HIP_TRY(c, up(&c->d_lights, s->lights, sizeof(iris_light) * s->n_lights));
+    c->sc.spheres = (const float4 *)c->d_spheres;
+    c->sc.prim_info = (const int2 *)c->d_prim_info;
+    c->sc.bsdfs = (const iris_bsdf *)c->d_bsdfs;
+    c->sc.spectra = (const iris_spectrum *)c->d_spectra;
+    c->sc.lights = (const iris_light *)c->d_lights;
+    c->sc.n_prims = s->n_prims;
+    c->sc.n_lights = s->n_lights;
+    c->have_scene = true;
+    return IRIS_OK;
+}
+
+int iris_render_device(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *d_out, void *stream) {
+    if (!c) return IRIS_E_ARG;
+    return render_impl(c, cam, p, d_out, (hipStream_t)stream);
+}
+
+int iris_render(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *out_xyz) {
+    if (!c) return IRIS_E_ARG;
+    int rc;
+    if ((rc = check_params(c, p))) return rc;
+    if (!out_xyz) return fail(c, IRIS_E_ARG, "out_xyz is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)p->width * p->height * 3;
+    float *d_out = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_out, n * sizeof(float)));
+    rc = render_impl(c, cam, p, d_out, nullptr);
+    if (rc == IRIS_OK) {
+        hipError_t e = hipMemcpy(out_xyz, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, IRIS_E_HIP, std::string("hipMemcpy film: ") + hipGetErrorString(e));
+    }
+    dev_free(d_out);
+    return rc;
+}
+
+int iris_get_stats(const iris_ctx *c, iris_stats *out) {
+    if (!c || !out) return IRIS_E_ARG;
+    *out = c->stats;
+    return IRIS_OK;
+}
+
+// ---- debug / parity entry points ----
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { dev_free(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)); }
+};
+}  // namespace
+
+int iris_dbg_sampler(iris_ctx *c, uint32_t n, const uint32_t *xys, uint32_t seed, uint32_t ndraws, float *out) {
+    if (!c) return IRIS_E_ARG;
+    if (!xys || !out || n == 0 || ndraws == 0) return fail(c, IRIS_E_ARG, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf dx, dout;
+    HIP_TRY(c, dx.alloc(sizeof(uint32_t) * 3 * n));
+    HIP_TRY(c, dout.alloc(sizeof(float) * (size_t)n * ndraws));
+    HIP_TRY(c, hipMemcpy(dx.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dbg_sampler, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, nullptr, (const uint32_t *)dx.p, n, seed, ndraws, (float *)dout.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(out, dout.p, sizeof(float) * (size_t)n * ndraws, hipMemcpyDeviceToHost));
+    return IRIS_OK;
+}
+
+int iris_dbg_raygen(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, uint32_t n, const uint32_t *xys, float *hero_out,
+                    float *ray_o, float *ray_d) {
+    if (!c) return IRIS_E_ARG;
+    int rc;
+    if ((rc = check_params(c, p))) return rc;
+    if (!cam || !xys || !hero_out || !ray_o || !ray_d || n == 0) return fail(c, IRIS_E_ARG, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf dx, dh, dorig, ddir;
+    HIP_TRY(c, dx.alloc(sizeof(uint32_t) * 3 * n));
+    HIP_TRY(c, dh.alloc(sizeof(float) * 4 * n));
+    HIP_TRY(c, dorig.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(c, ddir.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(c, hipMemcpy(dx.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dbg_raygen, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, nullptr, cam_dev(cam), frame_dev(p), (const uint32_t *)dx.p, n,
+                       (float *)dh.p, (float *)dorig.p, (float *)ddir.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(hero_out, dh.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ray_o, dorig.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ray_d, ddir.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    return IRIS_OK;
+}
+
+int iris_dbg_intersect(iris_ctx *c, uint32_t n, const float *ray_o, const float *ray_d, int32_t *prim, float *t) {
+    if (!c) return IRIS_E_ARG;
+    if (!c->have_scene) return fail(c, IRIS_E_STATE, "no scene uploaded");
+    if (!ray_o || !ray_d || !prim || !t || n == 0) return fail(c, IRIS_E_ARG, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf dorig, ddir, dp, dt;
+    HIP_TRY(c, dorig.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(c, ddir.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(c, dp.alloc(sizeof(int32_t) * n));
+    HIP_TRY(c, dt.alloc(sizeof(float) * n));
+    HIP_TRY(c, hipMemcpy(dorig.p, ray_o, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(ddir.p, ray_d, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    uint32_t cap = sphere_cap_for(c);
+    hipLaunchKernelGGL(k_dbg_intersect, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), (size_t)cap * sizeof(float4), nullptr, c->sc, cap,
+                       (const float *)dorig.p, (const float *)ddir.p, n, (int32_t *)dp.p, (float *)dt.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(prim, dp.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(t, dt.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return IRIS_OK;
+}
+
+int iris_dbg_trace(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, uint32_t n, const uint32_t *xys, iris_trace *out) {
+    if (!c) return IRIS_E_ARG;
+    int rc;
+    if ((rc = check_params(c, p))) return rc;
+    if ((rc = check_scene_for(c, p))) return rc;
+    if (!cam || !xys || !out || n == 0) return fail(c, IRIS_E_ARG, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf dx, dtr;
+    HIP_TRY(c, dx.alloc(sizeof(uint32_t) * 3 * n));
+    HIP_TRY(c, dtr.alloc(sizeof(iris_trace) * (size_t)n));
+    HIP_TRY(c, hipMemcpy(dx.p, xys, sizeof(uint32_t) * 3 * n, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(dtr.p, 0, sizeof(iris_trace) * (size_t)n));
+    uint32_t cap = sphere_cap_for(c);
+    dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
+    size_t dyn = (size_t)cap * sizeof(float4);
+    CamDev cd = cam_dev(cam);
+    FrameDev fd = frame_dev(p);
+    switch (p->integrator) {
+    case IRIS_INT_HWSS_NAIVE: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_HWSS_NAIVE>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
+    case IRIS_INT_HWSS_SLOW: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_HWSS_SLOW>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
+    case IRIS_INT_SWSS_NAIVE: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_SWSS_NAIVE>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
+    default: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_SWSS_SLOW>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(out, dtr.p, sizeof(iris_trace) * (size_t)n, hipMemcpyDeviceToHost));
+    return IRIS_OK;
+}
+
+}  // extern "C"
