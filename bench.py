@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Headline benchmark: whole-node Msamples/s of the path-tracing hot path (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one full pass of the hot path over the workload: BASELINE config B, the reference's default
+scene (scene.rs:43-66) at 1920x1080 with 1024 samples per pixel PER GPU (weak scaling: at N GPUs the
+film is rendered at 1024*N spp, rank r takes sample indices [1024 r, 1024 (r+1)), and the partial films
+are summed with one RCCL all-reduce inside the timed region).  Scene, camera and film live in HBM before
+the timed region starts; nothing is copied to the host inside it.
+
+Msamples/s = W*H*spp / 1e6 / seconds, the definition main.rs:109-114 prints.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic flop model (DESIGN.md "Roofline"): FMA = 2, sqrt/div/sin/cos = 1.
+F_CAM, F_ISECT, F_FRAME, F_SHADE = 120.0, 27.0, 44.0, 400.0
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (vector)"
+
+
+def algorithmic_flops(st):
+    return F_CAM * st.samples + F_ISECT * st.sphere_tests + (F_FRAME + F_SHADE) * st.bounces
+
+
+def cpu_baseline(n_threads):
+    """The oracle (a C port of the reference's CPU path, oracle/iris_oracle.c) timed on this host's cores
+    on BASELINE config A: 512x512 at 64 spp, default scene, HwssNaive."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_ffi as O
+    from iris_amd import Scene
+    O.set_trig_mode(O.TRIG_LIBM)
+    w = h = 512
+    spp = 64
+    sc = O.OracleScene(Scene.dummy().flatten())
+    cam = O.camera_new([0, 0, 0], np.float32(1.0))
+    _, _, secs, st = sc.render(cam, O.make_params(w, h, spp), nthreads=n_threads)
+    return {"value": round(w * h * spp / 1e6 / secs, 3), "unit": "Msamples/s", "cores": n_threads, "kind": "port",
+            "sample": "BASELINE config A: default scene 512x512 at 64 spp (16.8 Msamples), HwssNaive, oracle C port, "
+                      "%d threads popping 64x64 tiles, %.2f s" % (n_threads, secs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU")
+    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi-kernel", action="store_true", help="launch the two stages as separate kernels")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import iris_amd
+    from iris_amd.distributed import sample_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[args.scene]()
+    max_depth = 32 if args.scene == "s3" else iris_amd.scene.MAX_DEPTH
+    spp_total = args.spp * world
+    render = iris_amd.Render(args.width, args.height, spp_total, scene, max_depth=max_depth)
+    gpu = iris_amd.HipWavefront(device=local_rank, multi_kernel=1 if args.multi_kernel else 0)
+    gpu.upload(scene)
+    film = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device="cuda")
+    begin, count = sample_range(spp_total, rank, world)
+
+    def step():
+        gpu.render_film_device(render, film.data_ptr(), spp_begin=begin, spp_count=count)
+        if world > 1:
+            dist.all_reduce(film, op=dist.ReduceOp.SUM)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, flops, st = 0.0, 0.0, None
+    for _ in range(args.steps):
+        step()
+        st = gpu.stats()
+        kernel_ms += st.kernel_ms
+        flops += algorithmic_flops(st)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        samples_per_step = args.width * args.height * spp_total
+        value = samples_per_step * args.steps / 1e6 / elapsed
+        achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config B per GPU: %s scene %dx%d, %d spp per GPU (%d spp total), HwssNaive, "
+                                   "max_depth %d, spp-split + RCCL all-reduce of the XYZ film" %
+                                   ({"s1": "default (scene.rs:43-66, 3 spheres)", "s2": "10k-sphere", "s3": "glossy/dielectric"}[args.scene],
+                                    args.width, args.height, args.spp, spp_total, max_depth),
+                       "width": args.width, "height": args.height, "spp_per_gpu": args.spp, "parallelism": "spp-split x%d" % world},
+            # rank 0's path-tracing kernel (k_wavefront), timed with HIP events on its own stream inside the library
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "kernel": "k_wavefront<HwssNaive>", "kernel_ms_per_launch": round(kernel_ms / args.steps / max(1, st.chunks), 3),
+                         "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters)"},
+            "rays_per_s": round(st.rays / (kernel_ms / args.steps * 1e-3), 1) if kernel_ms else None,
+            "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
+            line["cpu_baseline"] = cpu_baseline(n_threads)
+        print(json.dumps(line), flush=True)
+    gpu.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/iris_hip.h
+declares, and its host-side helpers (camera, roughness mapping, XYZ->RGB) agree bit for bit with the
+oracle.  No compute entry point is called here (there is no GPU in this run)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def test_library_exports_every_declared_symbol():
+    from iris_amd import ffi
+    header = open(os.path.join(ROOT, "include", "iris_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int|void|float)\s*\*?\s*(iris_\w+)\s*\(", header, re.M))
+    assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
+    L = C.CDLL(ffi.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_abi_struct_sizes():
+    from iris_amd import ffi
+    assert C.sizeof(ffi.Sphere) == 16 and C.sizeof(ffi.Spectrum) == 20 and C.sizeof(ffi.Bsdf) == 20
+    assert C.sizeof(ffi.Light) == 8 and C.sizeof(ffi.Camera) == 76 and C.sizeof(ffi.RenderParams) == 36
+    assert C.sizeof(ffi.Trace) == 4 * (4 + 3 + 3 + 4 + 3 + 1 + 64 + 64 + 1)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without a HIP device the context cannot be created and says so."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import iris_amd
+    with pytest.raises(iris_amd.IrisError):
+        iris_amd.HipWavefront(device=0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under iris_amd/, include/ or bench.py's product leg may use oracle/."""
+    for base, _, files in os.walk(os.path.join(ROOT, "iris_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp", ".inc")):
+                text = open(os.path.join(base, f)).read()
+                assert "oracle_ffi" not in text and "liboracle" not in text and "iris_oracle" not in text, f
+
+
+@pytest.mark.parametrize("aspect", [1.0, 16.0 / 9.0, 3840.0 / 2160.0, 0.75])
+def test_camera_matches_oracle(oracle, aspect):
+    """iris_camera_new (camera.rs:10-21) == the oracle's restatement, bit for bit."""
+    import iris_amd
+    for pos in ([0, 0, 0], [0.5, -1.25, 2.0]):
+        cam = iris_amd.Camera(pos, np.float32(aspect))
+        ocam = oracle.camera_new(pos, np.float32(aspect))
+        assert np.array_equal(bits(cam.clip_to_world.ravel()), bits(np.array(ocam.clip_to_world)))
+        assert np.array_equal(cam.position, np.array(ocam.position, np.float32))
+
+
+def test_roughness_to_alpha_matches_oracle(oracle):
+    from iris_amd import ffi
+    L = ffi.load()
+    for r in (1e-4, 1e-3, 0.05, 0.2, 0.5, 1.0):
+        a = L.iris_roughness_to_alpha(C.c_float(r))
+        assert a == oracle.lib().orc_roughness_to_alpha(C.c_float(r))
+    assert abs(L.iris_roughness_to_alpha(C.c_float(1.0)) - 1.62142) < 1e-6
+
+
+def test_film_to_rgb_matches_oracle(oracle):
+    import iris_amd
+    rng = np.random.RandomState(0)
+    xyz = rng.uniform(-0.2, 3.0, size=(5, 7, 3)).astype(np.float32)
+    xyz[0, 0] = np.nan
+    rgb = iris_amd.film_to_rgb(xyz)
+    want = np.zeros_like(xyz)
+    fp = C.POINTER(C.c_float)
+    for i in range(5):
+        for j in range(7):
+            o = np.zeros(3, np.float32)
+            oracle.lib().orc_xyz_to_rgb_hdr(xyz[i, j].ctypes.data_as(fp), o.ctypes.data_as(fp))
+            want[i, j] = np.where(np.isnan(o), 0.0, np.maximum(o, 0.0))  # f32::max(0.0), tile.rs:109
+    assert np.array_equal(bits(rgb), bits(want))
+    assert np.all(rgb >= 0.0)
+
+
+def test_scene_flattening():
+    """Scene.dummy() mirrors scene.rs:43-66: 3 primitives, 3 materials, 1 light on primitive 0."""
+    from iris_amd import Scene, scene as S
+    flat = Scene.dummy().flatten()
+    assert flat.spheres.tolist() == [[0.0, np.float32(2.3), 3.0, 1.0], [0.0, np.float32(-0.2), 3.0, 1.0], [0.0, -101.5, 2.0, 100.0]]
+    assert flat.prim_material.tolist() == [0, 1, 2] and flat.prim_light.tolist() == [0, -1, -1]
+    assert [b[0] for b in flat.bsdfs] == [S.BSDF_LAMBERTIAN] * 3
+    assert len(flat.lights) == 1 and flat.lights[0][1] == 0
+    assert flat.spectra[flat.lights[0][0]] == (S.SPEC_CONSTANT, 3.0, 0.0, 0.0, 0.0)
+    desc, keep = flat.to_desc()
+    assert desc.n_prims == 3 and desc.n_bsdfs == 3 and desc.n_lights == 1 and desc.n_spectra == 4
+    s2 = Scene.many_spheres(300)
+    f2 = s2.flatten()
+    assert len(f2.spheres) == 300 and f2.prim_light.tolist().count(0) == 1
+    assert np.array_equal(f2.spheres, Scene.many_spheres(300).flatten().spheres)  # deterministic generator
+    s3 = Scene.glossy_dielectric().flatten()
+    assert [b[0] for b in s3.bsdfs] == [S.BSDF_LAMBERTIAN, S.BSDF_FRESNEL, S.BSDF_LAMBERTIAN, S.BSDF_MICROFACET, S.BSDF_SPECULAR]
