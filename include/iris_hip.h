@@ -154,6 +154,13 @@ const char *iris_last_error(const iris_ctx *ctx);
  *   "result_bytes"    cap on the per-sample result buffer (default 64 GiB)
  *   "multi_kernel"    1: launch the two stages as separate kernels (for profiling);
  *                     0: one persistent kernel (default)
+ *   "mode"            0: choose by scene size (default); 1: pool/queue kernels (path state in HBM/L2,
+ *                     rays compacted before every scan); 2: register-resident kernel (needs the
+ *                     sphere list to fit the LDS window)
+ *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 32)
+ *   "shade_threshold" register-resident kernel: lanes of a wave that must hold a hit before a shade
+ *                     phase runs (default 52)
+ * None of them changes a single bit of the result.
  */
 int iris_ctx_set_option(iris_ctx *ctx, const char *key, int64_t value);
 

@@ -67,6 +67,7 @@ struct WfArgs {
     uint32_t items_per_block;
     uint32_t slots_per_block;
     uint32_t sphere_cap;      // LDS window, in spheres
+    uint32_t shade_threshold; // register-resident kernel: lanes holding a hit before a shade phase runs
 };
 
 struct BlockShared {
@@ -120,6 +121,8 @@ __device__ __forceinline__ void flush_counters(const WfArgs &a, const Counters &
     }
 }
 
+__device__ __forceinline__ unsigned long long item_of(const WfArgs &a, uint32_t k);
+
 // ---- stage A: refill dead slots, generate camera rays, closest hit, compact hits into the queue ----
 template <int INTEG>
 __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereStage &st, SobolLds tab, BlockShared &bs, Counters &cnt) {
@@ -129,14 +132,15 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
         float4 rd = a.pool.rayd[slot];
         const bool was_alive = (__float_as_uint(rd.w) & STATE_ALIVE) != 0u;
         // refill: dead lanes take the next items of this workgroup's range
-        const uint32_t id = wave_reserve(!was_alive, &bs.cursor);
-        const bool regen = !was_alive && id < bs.w_end;
+        const uint32_t k = wave_reserve(!was_alive, &bs.cursor);
+        const unsigned long long id = item_of(a, k);
+        const bool regen = !was_alive && k < bs.w_end && id < a.n_items;
         PathState ps;
         uint32_t item = 0u;
         if (regen) {
-            item = id;
-            uint32_t s_local = id / a.npix;
-            uint32_t pix = id - s_local * a.npix;
+            item = (uint32_t)id;
+            uint32_t s_local = item / a.npix;
+            uint32_t pix = item - s_local * a.npix;
             uint32_t y = pix / a.fr.width;
             uint32_t x = pix - y * a.fr.width;
             raygen(a.cam, a.fr, tab, x, y, a.s_begin + s_local, ps);
@@ -239,18 +243,24 @@ __device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &
     }
 }
 
+// Items are dealt to the workgroups in runs of 64 consecutive items, round-robin, so that every
+// workgroup sees a representative mix of the image (sky rows are cheap, ground rows expensive) and all
+// of them finish together.  The k-th item of workgroup b is item_of(k); ids beyond n_items (last round
+// only) are skipped.
 __device__ __forceinline__ void block_range(const WfArgs &a, uint32_t &begin, uint32_t &end) {
-    unsigned long long b = (unsigned long long)blockIdx.x * a.items_per_block;
-    unsigned long long e = b + a.items_per_block;
-    if (b > a.n_items) b = a.n_items;
-    if (e > a.n_items) e = a.n_items;
-    begin = (uint32_t)b;
-    end = (uint32_t)e;
+    begin = 0u;
+    end = a.items_per_block;
+}
+__device__ __forceinline__ unsigned long long item_of(const WfArgs &a, uint32_t k) {
+    return (unsigned long long)(k >> 6) * ((unsigned long long)gridDim.x << 6) + ((unsigned long long)blockIdx.x << 6) + (k & 63u);
 }
 
 // ---- the persistent kernel: both stages in a loop, one workgroup = one independent wavefront tracer ----
+#ifndef IRIS_WAVES_PER_EU
+#define IRIS_WAVES_PER_EU 2
+#endif
 template <int INTEG>
-__global__ void __launch_bounds__(BLOCK) k_wavefront(WfArgs a) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS_WAVES_PER_EU, IRIS_WAVES_PER_EU))) k_wavefront(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
     __shared__ BlockShared bs;
@@ -274,6 +284,97 @@ __global__ void __launch_bounds__(BLOCK) k_wavefront(WfArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) bs.qn = 0u;
         __syncthreads();
+    }
+    flush_counters(a, cnt);
+}
+
+
+// ---- the register-resident variant for sphere lists that fit the LDS window ----
+// Same per-lane device code, but the path state never leaves the registers: every lane owns one path,
+// there is no pool, no queue and no workgroup barrier in the loop, so waves run independently.  A wave
+// alternates between two wave-uniform phases, chosen by a ballot of the lane states:
+//   gen/extend: dead lanes take the next items of the workgroup's list (ballot + prefix sum + one LDS
+//               atomic per wave) and generate their camera ray; every lane holding a ray intersects it;
+//   shade:      run once at least `shade_threshold` lanes hold a hit (or nothing else can make progress).
+// Repeating the cheap gen/extend phase until most lanes hold a hit is what keeps the expensive shade
+// phase well filled without moving any state between lanes.
+enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u };
+
+template <int INTEG>
+__global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
+    extern __shared__ float4 sphere_win[];
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ BlockShared bs;
+    stage_tables(sobol_lds);
+    SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
+    st.resident = true;  // launched only when the whole list is in the window: no barrier inside the scans
+    if (threadIdx.x == 0) {
+        block_range(a, bs.cursor, bs.w_end);
+        bs.qn = 0u;
+    }
+    __syncthreads();
+    const uint32_t w_end = bs.w_end;
+    Counters cnt = {0u, 0u, 0u, 0u};
+    PathState ps;
+    ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
+    ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
+    ps.smp = sampler_new(0u, 0u, 0u, 0u);
+    uint32_t lane_state = LANE_DEAD, item = 0u;
+    int prim = -1;
+    float t = 0.0f;
+    bool work_left = true;  // wave-uniform
+    for (;;) {
+        const uint32_t n_hit = (uint32_t)__popcll(__ballot(lane_state == LANE_HIT));
+        const uint32_t n_ray = (uint32_t)__popcll(__ballot(lane_state == LANE_RAY));
+        const uint32_t n_dead = 64u - n_hit - n_ray;
+        const bool can_extend = n_ray != 0u || (n_dead != 0u && work_left);
+        if (n_hit >= a.shade_threshold || !can_extend) {
+            if (n_hit == 0u) break;  // nothing in flight and nothing left to start
+            const bool active = lane_state == LANE_HIT;
+            const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, sobol_lds, active, ps, prim, t, cnt);
+            if (active) {
+                if (cont) {
+                    lane_state = LANE_RAY;
+                } else {
+                    store_result(a, item, path_xyz<INTEG>(ps));
+                    lane_state = LANE_DEAD;
+                }
+            }
+        } else {
+            if (work_left && n_dead != 0u) {
+                const bool need = lane_state == LANE_DEAD;
+                const uint32_t k = wave_reserve(need, &bs.cursor);
+                const unsigned long long id = item_of(a, k);
+                if (need && k < w_end && id < a.n_items) {
+                    item = (uint32_t)id;
+                    uint32_t s_local = item / a.npix;
+                    uint32_t pix = item - s_local * a.npix;
+                    uint32_t y = pix / a.fr.width;
+                    uint32_t x = pix - y * a.fr.width;
+                    raygen(a.cam, a.fr, sobol_lds, x, y, a.s_begin + s_local, ps);
+                    cnt.samples++;
+                    lane_state = LANE_RAY;
+                }
+                // the list is handed out in ascending k: once any lane was refused, it is exhausted
+                work_left = __ballot(need && k >= w_end) == 0ull;
+            }
+            const bool active = lane_state == LANE_RAY;
+            float t_new;
+            int prim_new;
+            scan_closest(a.sc, st, active, ps.ray, t_new, prim_new);
+            if (active) {  // lanes already holding a hit keep theirs
+                cnt.rays++;
+                cnt.sphere_tests += a.sc.n_prims;
+                t = t_new;
+                prim = prim_new;
+                if (prim >= 0) {
+                    lane_state = LANE_HIT;
+                } else {  // `None => break` (hwss_naive.rs:41-44)
+                    store_result(a, item, path_xyz<INTEG>(ps));
+                    lane_state = LANE_DEAD;
+                }
+            }
+        }
     }
     flush_counters(a, cnt);
 }
@@ -444,6 +545,9 @@ struct iris_ctx {
     int64_t slots_per_block = 1024;
     int64_t result_bytes = 64ll << 30;
     int64_t multi_kernel = 0;
+    int64_t mode = 0;             // 0 auto, 1 pool/queue kernels, 2 register-resident kernel
+    int64_t shade_threshold = 52;
+    int64_t reg_blocks_per_cu = 32;  // register-resident kernel: more workgroups than fit, for a short tail
     // scene
     bool have_scene = false;
     SceneDev sc = {};
@@ -545,9 +649,25 @@ FrameDev frame_dev(const iris_render_params *p) {
 }
 uint32_t sphere_cap_for(const iris_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->sc.n_prims, 1u), SPHERE_CAP); }
 
+// The register-resident kernel needs the whole sphere list in the LDS window; it is the default for
+// short lists (where shading, not the scans, is the cost), the pool/queue kernels for long ones (where
+// compacting rays before every scan pays).
+constexpr uint32_t REGISTER_KERNEL_MAX_PRIMS = 64;
+bool use_register_kernel(const iris_ctx *c) {
+    if (c->multi_kernel || c->mode == 1) return false;
+    if (c->sc.n_prims > SPHERE_CAP) return false;
+    return c->mode == 2 || c->sc.n_prims <= REGISTER_KERNEL_MAX_PRIMS;
+}
+
 template <int INTEG>
 int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stream) {
     size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
+    if (use_register_kernel(c)) {
+        hipLaunchKernelGGL(k_regwave<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        HIP_TRY(c, hipGetLastError());
+        c->stats.launches += 1;
+        return IRIS_OK;
+    }
     if (!c->multi_kernel) {
         hipLaunchKernelGGL(k_wavefront<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
         HIP_TRY(c, hipGetLastError());
@@ -600,9 +720,10 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         if ((rc = dev_alloc(c, &c->d_film_acc, (size_t)npix))) return rc;
         c->film_cap = npix;
     }
-    uint32_t blocks = (uint32_t)(c->n_cus * c->blocks_per_cu);
+    const bool reg = use_register_kernel(c);
+    uint32_t blocks = (uint32_t)(c->n_cus * (reg ? c->reg_blocks_per_cu : c->blocks_per_cu));
     uint32_t spb = (uint32_t)c->slots_per_block;
-    if ((rc = ensure_pools(c, blocks, spb))) return rc;
+    if (!reg && (rc = ensure_pools(c, blocks, spb))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), stream));
 
     const float weight = 1.0f / (float)p->spp_total;  // tile.rs:140
@@ -628,9 +749,10 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.npix = npix;
         a.s_begin = p->spp_begin + done;
         a.n_items = n_s * npix;
-        a.items_per_block = (a.n_items + blocks - 1) / blocks;
+        a.items_per_block = ((a.n_items + blocks * 64u - 1) / (blocks * 64u)) * 64u;  // whole runs of 64
         a.slots_per_block = spb;
         a.sphere_cap = sphere_cap_for(c);
+        a.shade_threshold = (uint32_t)c->shade_threshold;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
         switch (p->integrator) {
         case IRIS_INT_HWSS_NAIVE: rc = launch_chunk<IRIS_INT_HWSS_NAIVE>(c, a, blocks, stream); break;
@@ -720,6 +842,15 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
         c->result_bytes = value;
     } else if (k == "multi_kernel") {
         c->multi_kernel = value ? 1 : 0;
+    } else if (k == "mode") {
+        if (value < 0 || value > 2) return fail(c, IRIS_E_ARG, "mode must be 0 (auto), 1 (pool) or 2 (register)");
+        c->mode = value;
+    } else if (k == "reg_blocks_per_cu") {
+        if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "reg_blocks_per_cu out of range [1, 1024]");
+        c->reg_blocks_per_cu = value;
+    } else if (k == "shade_threshold") {
+        if (value < 1 || value > 64) return fail(c, IRIS_E_ARG, "shade_threshold out of range [1, 64]");
+        c->shade_threshold = value;
     } else {
         return fail(c, IRIS_E_ARG, "unknown option " + k);
     }

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libiris_hip.so")
+# IRIS_HIP_LIB: alternative build of the same library (tuning experiments)
+LIB_PATH = os.environ.get("IRIS_HIP_LIB") or os.path.join(HERE, "lib", "libiris_hip.so")
 
 IRIS_OK = 0
 TRACE_MAX_DEPTH = 64

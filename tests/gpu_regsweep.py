@@ -1,0 +1,16 @@
+"""Ad-hoc (not collected): register-resident kernel tuning."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from iris_amd import HipWavefront, Render, Scene
+scene = Scene.dummy()
+W, H, SPP = 1920, 1080, int(os.environ.get("SPP", "256"))
+r = Render(W, H, SPP, scene)
+with HipWavefront(0, mode=1, blocks_per_cu=2, slots_per_block=2048) as g:
+    g.upload(scene); g.render_film(r); ref = g.render_film(r); st = g.stats()
+    print("pool 2x2048: kernel %8.2f ms %8.1f Msamples/s" % (st.kernel_ms, W * H * SPP / st.kernel_ms / 1e3), flush=True)
+for rb in (32,):
+    for thr in (44, 52):
+        with HipWavefront(0, mode=2, reg_blocks_per_cu=rb, shade_threshold=thr) as g:
+            g.upload(scene); g.render_film(r); film = g.render_film(r); st = g.stats()
+            print("reg blocks/cu %3d thr %2d: kernel %8.2f ms %8.1f Msamples/s same=%s" % (rb, thr, st.kernel_ms, W * H * SPP / st.kernel_ms / 1e3, np.array_equal(film, ref)), flush=True)

@@ -10,7 +10,8 @@ out = sys.argv[1]
 
 
 def short(name):
-    return name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    name = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    return name.split("(")[0]
 
 
 print("== kernel-trace stats (rocprofv3 --kernel-trace --stats) ==")
