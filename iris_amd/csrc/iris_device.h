@@ -264,18 +264,22 @@ IRIS_DEV Sampler sampler_new(uint32_t x, uint32_t y, uint32_t sample_index, uint
     s.q0 = s.q1 = s.q2 = 0.0f; s.in_buffer = 0u; s.draws = 0u;
     return s;
 }
-__device__ __noinline__ float sampler_refill(SobolLds tab, Sampler &s) {  // sampler.rs:27-46
+// One 4-D set: returns the value popped first (buf[3]) and the three that stay buffered.  Out of line
+// (it is called from nine places), with everything passed and returned in registers.
+struct Refill { float first, q0, q1, q2; };
+#ifndef IRIS_REFILL_ATTR
+#define IRIS_REFILL_ATTR __noinline__
+#endif
+__device__ IRIS_REFILL_ATTR Refill sampler_refill(SobolLds tab, uint32_t index, uint32_t dimension, uint32_t scramble) {  // sampler.rs:27-46
     float b[4];
-    if (s.dimension < IRIS_SOBOL_SETS) {
-        sobol_sample_4d(tab, s.index, s.dimension, hash_u32(s.dimension, s.scramble), b);
+    if (dimension < IRIS_SOBOL_SETS) {
+        sobol_sample_4d(tab, index, dimension, hash_u32(dimension, scramble), b);
     } else {  // sampler.rs:36-41 (from set 64 on: docs/SPEC.md)
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) b[k] = hash_u32_to_f32((s.dimension + k) ^ (s.index << 16), s.scramble);
+        for (uint32_t k = 0; k < 4; k++) b[k] = hash_u32_to_f32((dimension + k) ^ (index << 16), scramble);
     }
-    s.dimension += 1u;
-    s.in_buffer = 3u;
-    s.q0 = b[0]; s.q1 = b[1]; s.q2 = b[2];
-    return b[3];
+    Refill r = {b[3], b[0], b[1], b[2]};
+    return r;
 }
 IRIS_DEV float gen_0_1(SobolLds tab, Sampler &s) {  // sampler.rs:23-50: values pop in reverse
     s.draws++;
@@ -285,7 +289,11 @@ IRIS_DEV float gen_0_1(SobolLds tab, Sampler &s) {  // sampler.rs:23-50: values 
         s.in_buffer -= 1u;
         return r;
     }
-    return sampler_refill(tab, s);
+    Refill r = sampler_refill(tab, s.index, s.dimension, s.scramble);
+    s.dimension += 1u;
+    s.in_buffer = 3u;
+    s.q0 = r.q0; s.q1 = r.q1; s.q2 = r.q2;
+    return r.first;
 }
 IRIS_DEV float gen_golden_ratio(const Sampler &s) {  // sampler.rs:65-71 (u32::MAX as f32 == 2^32)
     uint32_t u = (s.index + s.scramble) * 2654435769u;
