@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--multi-kernel", action="store_true", help="launch the two stages as separate kernels")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="iris_ctx_set_option tuning knob (repeatable)")
     args = ap.parse_args()
 
     import torch
@@ -80,7 +81,10 @@ def main():
     max_depth = 32 if args.scene == "s3" else iris_amd.scene.MAX_DEPTH
     spp_total = args.spp * world
     render = iris_amd.Render(args.width, args.height, spp_total, scene, max_depth=max_depth)
-    gpu = iris_amd.HipWavefront(device=local_rank, multi_kernel=1 if args.multi_kernel else 0)
+    opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.opt}
+    if args.multi_kernel:
+        opts["multi_kernel"] = 1
+    gpu = iris_amd.HipWavefront(device=local_rank, **opts)
     gpu.upload(scene)
     film = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device="cuda")
     begin, count = sample_range(spp_total, rank, world)
@@ -126,10 +130,10 @@ def main():
                                    ({"s1": "default (scene.rs:43-66, 3 spheres)", "s2": "10k-sphere", "s3": "glossy/dielectric"}[args.scene],
                                     args.width, args.height, args.spp, spp_total, max_depth),
                        "width": args.width, "height": args.height, "spp_per_gpu": args.spp, "parallelism": "spp-split x%d" % world},
-            # rank 0's path-tracing kernel (k_wavefront), timed with HIP events on its own stream inside the library
+            # rank 0's path-tracing kernel, timed with HIP events on its own stream inside the library
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
-                         "kernel": "k_wavefront<HwssNaive>", "kernel_ms_per_launch": round(kernel_ms / args.steps / max(1, st.chunks), 3),
+                         "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / args.steps / max(1, st.chunks), 3),
                          "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters)"},
             "rays_per_s": round(st.rays / (kernel_ms / args.steps * 1e-3), 1) if kernel_ms else None,
             "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests},

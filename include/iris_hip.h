@@ -125,7 +125,16 @@ typedef struct {
     double resolve_ms;     /* HIP-event time of the film resolve kernels */
     uint32_t launches;     /* path-tracing kernel launches */
     uint32_t chunks;       /* sample-range chunks the render was split into */
+    uint32_t kernel;       /* which kernel traced the paths: enum iris_kernel_variant */
+    uint32_t reserved;
 } iris_stats;
+
+enum iris_kernel_variant {
+    IRIS_KERNEL_POOL_FUSED = 0,   /* k_wavefront: pool/queue stages in one persistent kernel */
+    IRIS_KERNEL_POOL_STAGES = 1,  /* k_stage_gen_extend + k_stage_shade launched alternately */
+    IRIS_KERNEL_REGISTER = 2,     /* k_regwave: path state in registers */
+    IRIS_KERNEL_REGISTER_QUEUE = 3 /* k_regqueue: registers + per-wave LDS hit queue */
+};
 
 /* One traced camera sample, for stage-level parity tests (iris_dbg_trace). */
 #define IRIS_TRACE_MAX_DEPTH 64
@@ -158,6 +167,8 @@ const char *iris_last_error(const iris_ctx *ctx);
  *                     rays compacted before every scan); 2: register-resident kernel (needs the
  *                     sphere list to fit the LDS window)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 32)
+ *   "reg_queue"       register-resident kernel: 1 = variant that parks hits in a per-wave LDS queue so
+ *                     that shade phases run with full waves (default 0: measured slower)
  *   "shade_threshold" register-resident kernel: lanes of a wave that must hold a hit before a shade
  *                     phase runs (default 52)
  * None of them changes a single bit of the result.

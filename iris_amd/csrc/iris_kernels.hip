@@ -379,6 +379,142 @@ __global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
     flush_counters(a, cnt);
 }
 
+
+// ---- register-resident kernel with a per-wave hit queue in LDS ----
+// As k_regwave, but a lane does not wait holding a hit: the gen/extend phase pushes every hit, with its
+// whole path state, into a ring queue in LDS that belongs to the wave (ballot + prefix sum give each
+// hit its entry; no other wave touches the queue, so there is no synchronisation at all), and frees the
+// lane for the next camera ray.  Once 64 hits are queued the wave pops them, one per free lane, and
+// shades with every lane busy.  Survivors keep their new ray in registers and are extended by the next
+// gen/extend phase.  The number of rays in flight in a wave is capped at the free queue entries, so the
+// queue cannot overflow.  96 entries per wave keep three workgroups per CU resident.
+constexpr uint32_t HITQ_FIELDS = 29;  // dwords of path state per queued hit
+constexpr uint32_t HITQ_CAP = 96;     // entries per wave
+
+#ifndef IRIS_REGQUEUE_WAVES
+#define IRIS_REGQUEUE_WAVES 2
+#endif
+template <int INTEG>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS_REGQUEUE_WAVES, IRIS_REGQUEUE_WAVES))) k_regqueue(WfArgs a) {
+    extern __shared__ float4 sphere_win[];
+    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ BlockShared bs;
+    __shared__ uint32_t hitq[BLOCK / 64][HITQ_FIELDS][HITQ_CAP];
+    stage_tables(sobol_lds);
+    SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
+    st.resident = true;
+    if (threadIdx.x == 0) {
+        block_range(a, bs.cursor, bs.w_end);
+        bs.qn = 0u;
+    }
+    __syncthreads();
+    const uint32_t w_end = bs.w_end;
+    uint32_t(*q)[HITQ_CAP] = hitq[threadIdx.x / 64];
+    Counters cnt = {0u, 0u, 0u, 0u};
+    PathState ps;
+    ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
+    ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
+    ps.smp = sampler_new(0u, 0u, 0u, 0u);
+    uint32_t item = 0u;
+    bool has_ray = false;
+    bool work_left = true;               // wave-uniform
+    uint32_t q_head = 0u, q_count = 0u;  // wave-uniform
+    for (;;) {
+        const unsigned long long ray_mask = __ballot(has_ray);
+        const uint32_t n_ray = (uint32_t)__popcll(ray_mask);
+        const uint32_t n_free = 64u - n_ray;
+        const bool can_extend = n_ray != 0u || work_left;
+        if ((q_count >= 64u && n_free != 0u) || !can_extend) {
+            if (q_count == 0u) break;
+            // ---- shade phase: pop hits into the lanes that hold no ray ----
+            const uint32_t n = q_count < n_free ? q_count : n_free;
+            const uint32_t rank = prefix_below(~ray_mask);
+            const bool active = !has_ray && rank < n;
+            int prim = 0;
+            float t = 0.0f;
+            if (active) {
+                const uint32_t e = (q_head + rank) % HITQ_CAP;
+                ps.ray.o = v3(__uint_as_float(q[0][e]), __uint_as_float(q[1][e]), __uint_as_float(q[2][e]));
+                ps.ray.d = v3(__uint_as_float(q[3][e]), __uint_as_float(q[4][e]), __uint_as_float(q[5][e]));
+                ps.hero_nm = __uint_as_float(q[6][e]);
+                ps.thr = f4(__uint_as_float(q[7][e]), __uint_as_float(q[8][e]), __uint_as_float(q[9][e]), __uint_as_float(q[10][e]));
+                ps.ppdf = f4(__uint_as_float(q[11][e]), __uint_as_float(q[12][e]), __uint_as_float(q[13][e]), __uint_as_float(q[14][e]));
+                ps.rad = f4(__uint_as_float(q[15][e]), __uint_as_float(q[16][e]), __uint_as_float(q[17][e]), __uint_as_float(q[18][e]));
+                ps.smp.q0 = __uint_as_float(q[19][e]); ps.smp.q1 = __uint_as_float(q[20][e]); ps.smp.q2 = __uint_as_float(q[21][e]);
+                ps.smp.dimension = q[22][e] & 0xffffu; ps.smp.in_buffer = q[22][e] >> 16;
+                ps.smp.scramble = q[23][e]; ps.smp.index = q[24][e]; ps.smp.draws = 0u;
+                ps.bounce = q[25][e];
+                item = q[26][e];
+                prim = (int)q[27][e];
+                t = __uint_as_float(q[28][e]);
+            }
+            q_head = (q_head + n) % HITQ_CAP;
+            q_count -= n;
+            const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, sobol_lds, active, ps, prim, t, cnt);
+            if (active) {
+                if (cont) has_ray = true;
+                else store_result(a, item, path_xyz<INTEG>(ps));
+            }
+        } else {
+            // ---- gen/extend phase: at most `room` rays in flight, so that their hits fit the queue ----
+            const uint32_t room = HITQ_CAP - q_count;
+            if (work_left && n_ray < room) {
+                const uint32_t rank = prefix_below(~ray_mask);
+                const bool need = !has_ray && rank < room - n_ray;
+                const uint32_t k = wave_reserve(need, &bs.cursor);
+                const unsigned long long id = item_of(a, k);
+                if (need && k < w_end && id < a.n_items) {
+                    item = (uint32_t)id;
+                    uint32_t s_local = item / a.npix;
+                    uint32_t pix = item - s_local * a.npix;
+                    uint32_t y = pix / a.fr.width;
+                    uint32_t x = pix - y * a.fr.width;
+                    raygen(a.cam, a.fr, sobol_lds, x, y, a.s_begin + s_local, ps);
+                    cnt.samples++;
+                    has_ray = true;
+                }
+                work_left = __ballot(need && k >= w_end) == 0ull;
+            }
+            // extend the first `room` rays of the wave (all of them, except in the rare case that more
+            // than `room` lanes survived the last shade phase)
+            const unsigned long long ray_mask2 = __ballot(has_ray);
+            const bool ext = has_ray && prefix_below(ray_mask2) < room;
+            float t;
+            int prim;
+            scan_closest(a.sc, st, ext, ps.ray, t, prim);
+            if (ext) {
+                cnt.rays++;
+                cnt.sphere_tests += a.sc.n_prims;
+                if (prim < 0) store_result(a, item, path_xyz<INTEG>(ps));  // `None => break` (hwss_naive.rs:41-44)
+            }
+            const bool hitp = ext && prim >= 0;
+            const unsigned long long hmask = __ballot(hitp);
+            if (hitp) {
+                const uint32_t e = (q_head + q_count + prefix_below(hmask)) % HITQ_CAP;
+                q[0][e] = __float_as_uint(ps.ray.o.x); q[1][e] = __float_as_uint(ps.ray.o.y); q[2][e] = __float_as_uint(ps.ray.o.z);
+                q[3][e] = __float_as_uint(ps.ray.d.x); q[4][e] = __float_as_uint(ps.ray.d.y); q[5][e] = __float_as_uint(ps.ray.d.z);
+                q[6][e] = __float_as_uint(ps.hero_nm);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    q[7 + k][e] = __float_as_uint(ps.thr.v[k]);
+                    q[11 + k][e] = __float_as_uint(ps.ppdf.v[k]);
+                    q[15 + k][e] = __float_as_uint(ps.rad.v[k]);
+                }
+                q[19][e] = __float_as_uint(ps.smp.q0); q[20][e] = __float_as_uint(ps.smp.q1); q[21][e] = __float_as_uint(ps.smp.q2);
+                q[22][e] = ps.smp.dimension | (ps.smp.in_buffer << 16);
+                q[23][e] = ps.smp.scramble; q[24][e] = ps.smp.index;
+                q[25][e] = ps.bounce;
+                q[26][e] = item;
+                q[27][e] = (uint32_t)prim;
+                q[28][e] = __float_as_uint(t);
+            }
+            q_count += (uint32_t)__popcll(hmask);
+            if (ext) has_ray = false;  // queued as a hit or finished as a miss
+        }
+    }
+    flush_counters(a, cnt);
+}
+
 // ---- the same two stages as separate kernels (profiling / north-star layout) ----
 __global__ void __launch_bounds__(BLOCK) k_pool_init(WfArgs a) {
     const uint32_t slot0 = blockIdx.x * a.slots_per_block;
@@ -547,6 +683,7 @@ struct iris_ctx {
     int64_t multi_kernel = 0;
     int64_t mode = 0;             // 0 auto, 1 pool/queue kernels, 2 register-resident kernel
     int64_t shade_threshold = 52;
+    int64_t reg_queue = 0;        // register-resident kernel: 1 = per-wave LDS hit queue variant (measured slower: DESIGN.md)
     int64_t reg_blocks_per_cu = 32;  // register-resident kernel: more workgroups than fit, for a short tail
     // scene
     bool have_scene = false;
@@ -663,7 +800,8 @@ template <int INTEG>
 int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stream) {
     size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
     if (use_register_kernel(c)) {
-        hipLaunchKernelGGL(k_regwave<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        if (c->reg_queue) hipLaunchKernelGGL(k_regqueue<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        else hipLaunchKernelGGL(k_regwave<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
         HIP_TRY(c, hipGetLastError());
         c->stats.launches += 1;
         return IRIS_OK;
@@ -784,6 +922,8 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     c->stats.sphere_tests = h[3];
     c->stats.kernel_ms = trace_ms;
     c->stats.resolve_ms = resolve_ms;
+    c->stats.kernel = reg ? (c->reg_queue ? IRIS_KERNEL_REGISTER_QUEUE : IRIS_KERNEL_REGISTER)
+                          : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED);
     return IRIS_OK;
 }
 
@@ -848,6 +988,8 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "reg_blocks_per_cu") {
         if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "reg_blocks_per_cu out of range [1, 1024]");
         c->reg_blocks_per_cu = value;
+    } else if (k == "reg_queue") {
+        c->reg_queue = value ? 1 : 0;
     } else if (k == "shade_threshold") {
         if (value < 1 || value > 64) return fail(c, IRIS_E_ARG, "shade_threshold out of range [1, 64]");
         c->shade_threshold = value;

@@ -38,7 +38,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         ndisp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
 for k, cs in agg.items():
-    if not any(t in k for t in ("wavefront", "regwave", "stage", "resolve")):
+    if not k.startswith("k_"):
         continue
     print(k[:60])
     for c, v in sorted(cs.items()):
