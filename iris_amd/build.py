@@ -32,12 +32,27 @@ def needs_build():
 
 
 def build(force=False, extra=()):
-    if not force and not needs_build():
-        return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", LIB_PATH] + SOURCES
-    subprocess.check_call(cmd)
+    if force or needs_build():
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = [HIPCC] + FLAGS + list(extra) + ["-o", LIB_PATH] + SOURCES
+        subprocess.check_call(cmd)
+    build_cli(force)
     return LIB_PATH
+
+
+# The C++ host driver above the C ABI (iris_amd/host/: the mirror of the reference's main.rs + scene.rs).
+CLI_PATH = os.path.join(LIB_DIR, "iris_render")
+CLI_SOURCES = [os.path.join(HERE, "host", "iris_main.cpp")]
+CLI_DEPS = CLI_SOURCES + [os.path.join(HERE, "host", "iris_scene.hpp"), os.path.join(HERE, "..", "include", "iris_hip.h")]
+
+
+def build_cli(force=False):
+    if not force and os.path.exists(CLI_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(CLI_PATH) for d in CLI_DEPS + [LIB_PATH]):
+        return CLI_PATH
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-pthread", "-o", CLI_PATH] + CLI_SOURCES + \
+          ["-L" + LIB_DIR, "-liris_hip", "-Wl,-rpath,$ORIGIN"]
+    subprocess.check_call(cmd)
+    return CLI_PATH
 
 
 if __name__ == "__main__":

@@ -105,3 +105,45 @@ def test_scene_flattening():
     assert np.array_equal(f2.spheres, Scene.many_spheres(300).flatten().spheres)  # deterministic generator
     s3 = Scene.glossy_dielectric().flatten()
     assert [b[0] for b in s3.bsdfs] == [S.BSDF_LAMBERTIAN, S.BSDF_FRESNEL, S.BSDF_LAMBERTIAN, S.BSDF_MICROFACET, S.BSDF_SPECULAR]
+
+
+# ---- the C++ host driver (iris_amd/host/: mirror of main.rs + scene.rs above the C ABI) --------------
+
+def _cli():
+    from iris_amd import build
+    return build.build_cli()
+
+
+@pytest.mark.parametrize("name,ctor", [("dummy", "dummy"), ("furnace", "furnace"), ("glossy", "glossy_dielectric"), ("spheres10k", "many_spheres")])
+def test_cpp_host_scene_tables_equal_python_mirror(name, ctor):
+    """The C++ Scene (add_material / add_emissive_material / dummy ...) flattens to byte-identical tables
+    as the Python mirror, including the 10k-sphere generator."""
+    import subprocess
+    from iris_amd import Scene
+    out = subprocess.run([_cli(), "--scene", name, "--dump-scene"], check=True, capture_output=True, text=True).stdout.split("\n")
+    flat = getattr(Scene, ctor)().flatten()
+    hx = lambda v: float(np.float32(v)).hex()
+    want = []
+    for i, s in enumerate(flat.spheres):
+        want.append("prim %d %s %s %s %s %d %d" % (i, hx(s[0]), hx(s[1]), hx(s[2]), hx(s[3]), flat.prim_material[i], flat.prim_light[i]))
+    for i, b in enumerate(flat.bsdfs):
+        want.append("bsdf %d %d %d %d %s %s" % (i, b[0], b[1], b[2], hx(b[3]), hx(b[4])))
+    for i, s in enumerate(flat.spectra):
+        want.append("spectrum %d %d %s %s %s %s" % (i, s[0], hx(s[1]), hx(s[2]), hx(s[3]), hx(s[4])))
+    for i, l in enumerate(flat.lights):
+        want.append("light %d %d %d" % (i, l[0], l[1]))
+    # C's %a and Python's float.hex() print the same value differently: compare parsed
+    def parse(line):
+        return [float.fromhex(t) if "0x" in t else t for t in line.split()]
+    got = [parse(l) for l in out if l]
+    assert got == [parse(l) for l in want]
+
+
+def test_cpp_host_driver_fails_loudly_without_gpu(tmp_path):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([_cli(), "--width", "8", "--height", "8", "--spp", "1", "--out", str(tmp_path / "o.pfm")], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+    assert not (tmp_path / "o.pfm").exists()

@@ -344,3 +344,56 @@ def test_error_codes(gpu):
         bad.prim_material[1] = 7
         with pytest.raises(iris_amd.IrisError, match="prim_material"):
             g2.upload(bad)
+
+
+# ---- the C++ host driver -----------------------------------------------------------------------------
+
+def read_exr_rgb(path):
+    """Parser for the uncompressed scanline EXR the driver writes (3 FLOAT channels B, G, R)."""
+    import struct
+    b = open(path, "rb").read()
+    assert struct.unpack_from("<II", b, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        (size,) = struct.unpack_from("<i", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    pos += 1
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    assert attrs["compression"][1] == b"\0" and attrs["channels"][1][:2] == b"B\0"
+    offs = struct.unpack_from("<%dQ" % h, b, pos)
+    img = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        yy, size = struct.unpack_from("<ii", b, offs[y])
+        assert yy == y and size == 12 * w
+        row = np.frombuffer(b, np.float32, 3 * w, offs[y] + 8).reshape(3, w)
+        img[y] = row[::-1].T
+    return img
+
+
+def test_cpp_host_driver_film_equals_python_path(gpu, tmp_path):
+    """iris_render (the C++ mirror of main.rs) writes the same linear-RGB film as the Python host path,
+    bit for bit, as EXR and as PFM, on one context and with the sample range split over two contexts
+    (equal up to the f32 re-association of the partial sums)."""
+    import subprocess
+    from iris_amd import Render, Scene, build, film_to_rgb
+    cli = build.build_cli()
+    scene = Scene.dummy()
+    gpu.upload(scene)
+    want = film_to_rgb(gpu.render_film(Render(80, 48, 6, scene)))
+    exr, pfm = str(tmp_path / "o.exr"), str(tmp_path / "o.pfm")
+    out = subprocess.run([cli, "--width", "80", "--height", "48", "--spp", "6", "--out", exr], check=True, capture_output=True, text=True).stdout
+    assert "Starting render, 80x48@6spp..." in out and "m ray/s" in out
+    assert np.array_equal(bits(read_exr_rgb(exr)), bits(want))
+    subprocess.run([cli, "--width", "80", "--height", "48", "--spp", "6", "--out", pfm], check=True, capture_output=True)
+    raw = open(pfm, "rb").read()
+    head = b"PF\n80 48\n-1.0\n"
+    assert raw.startswith(head)
+    img = np.frombuffer(raw, np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
+    assert np.array_equal(bits(img), bits(want))
+    # two contexts on the same device stand in for two GPUs: sample ranges [0,3) and [3,6)
+    subprocess.run([cli, "--width", "80", "--height", "48", "--spp", "6", "--gpus", "2", "--share-device", "--out", pfm], check=True, capture_output=True)
+    img2 = np.frombuffer(open(pfm, "rb").read(), np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
+    assert np.allclose(img2, want, rtol=1e-5, atol=1e-6)
