@@ -132,8 +132,7 @@ typedef struct {
 enum iris_kernel_variant {
     IRIS_KERNEL_POOL_FUSED = 0,   /* k_wavefront: pool/queue stages in one persistent kernel */
     IRIS_KERNEL_POOL_STAGES = 1,  /* k_stage_gen_extend + k_stage_shade launched alternately */
-    IRIS_KERNEL_REGISTER = 2,     /* k_regwave: path state in registers */
-    IRIS_KERNEL_REGISTER_QUEUE = 3 /* k_regqueue: registers + per-wave LDS hit queue */
+    IRIS_KERNEL_REGISTER = 2      /* k_regwave: path state in registers, per-wave queue of primary hits in LDS */
 };
 
 /* One traced camera sample, for stage-level parity tests (iris_dbg_trace). */
@@ -167,10 +166,6 @@ const char *iris_last_error(const iris_ctx *ctx);
  *                     rays compacted before every scan); 2: register-resident kernel (needs the
  *                     sphere list to fit the LDS window)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 32)
- *   "reg_queue"       register-resident kernel: 1 = variant that parks hits in a per-wave LDS queue so
- *                     that shade phases run with full waves (default 0: measured slower)
- *   "shade_threshold" register-resident kernel: lanes of a wave that must hold a hit before a shade
- *                     phase runs (default 52)
  * None of them changes a single bit of the result.
  */
 int iris_ctx_set_option(iris_ctx *ctx, const char *key, int64_t value);

@@ -249,28 +249,29 @@ IRIS_DEV void sobol_sample_4d(SobolLds tab, uint32_t index, uint32_t set, uint32
     }
 }
 
-// sampler.rs:4-10.  The 4-entry buffer is a shift register (q2 is popped next) so that no
-// runtime-indexed array is needed.
+// sampler.rs:4-10.  The reference keeps a 4-entry buffer that is refilled by whichever gen_0_1 call
+// finds it empty.  On a wave that would run the (long) refill at every one of the nine call sites of a
+// bounce for the quarter of the lanes that happen to need it there.  Here the draw STREAM is the same
+// (value j of a path is element 3 - j%4 of set j/4: the reverse pop of sampler.rs:24-26), but it is
+// produced ahead of use at wave-uniform points (ensure_draws: once per camera sample and once per
+// bounce) into a 16-entry ring per lane in LDS, and gen_0_1 is one LDS read.
+#define IRIS_BLOCK 256
+#define IRIS_RING_SLOTS 16u
+typedef float *DrawRing;  // LDS: ring[slot * IRIS_BLOCK], already offset by threadIdx.x
 struct Sampler {
-    uint32_t scramble, dimension, index;
-    float q0, q1, q2;
-    uint32_t in_buffer;
-    uint32_t draws;
+    uint32_t scramble, index;
+    uint32_t draws;  // values consumed so far
+    uint32_t gen;    // values generated so far (a multiple of 4; set k holds values 4k .. 4k+3)
 };
 IRIS_DEV Sampler sampler_new(uint32_t x, uint32_t y, uint32_t sample_index, uint32_t seed) {  // sampler.rs:13-21
     Sampler s;
     s.scramble = hash_u32(x ^ (y << 16), seed);
-    s.dimension = 0u; s.index = sample_index;
-    s.q0 = s.q1 = s.q2 = 0.0f; s.in_buffer = 0u; s.draws = 0u;
+    s.index = sample_index;
+    s.draws = 0u; s.gen = 0u;
     return s;
 }
-// One 4-D set: returns the value popped first (buf[3]) and the three that stay buffered.  Out of line
-// (it is called from nine places), with everything passed and returned in registers.
-struct Refill { float first, q0, q1, q2; };
-#ifndef IRIS_REFILL_ATTR
-#define IRIS_REFILL_ATTR __noinline__
-#endif
-__device__ IRIS_REFILL_ATTR Refill sampler_refill(SobolLds tab, uint32_t index, uint32_t dimension, uint32_t scramble) {  // sampler.rs:27-46
+// One 4-D set in pop order: out[0] is the value popped first (buf[3] of sampler.rs:27-46).
+IRIS_DEV void sampler_set(SobolLds tab, uint32_t index, uint32_t dimension, uint32_t scramble, float out[4]) {
     float b[4];
     if (dimension < IRIS_SOBOL_SETS) {
         sobol_sample_4d(tab, index, dimension, hash_u32(dimension, scramble), b);
@@ -278,22 +279,32 @@ __device__ IRIS_REFILL_ATTR Refill sampler_refill(SobolLds tab, uint32_t index, 
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) b[k] = hash_u32_to_f32((dimension + k) ^ (index << 16), scramble);
     }
-    Refill r = {b[3], b[0], b[1], b[2]};
-    return r;
+    out[0] = b[3]; out[1] = b[2]; out[2] = b[1]; out[3] = b[0];
 }
-IRIS_DEV float gen_0_1(SobolLds tab, Sampler &s) {  // sampler.rs:23-50: values pop in reverse
-    s.draws++;
-    if (s.in_buffer > 0u) {
-        float r = s.q2;
-        s.q2 = s.q1; s.q1 = s.q0;
-        s.in_buffer -= 1u;
-        return r;
+// Makes at least `need` (<= 12) unread values available to an active lane.  Wave-uniform loop: every
+// lane that is short generates its next set in the same pass.
+IRIS_DEV void ensure_draws(SobolLds tab, DrawRing ring, Sampler &s, uint32_t need, bool active) {
+    for (;;) {
+        // signed: after sampler_rewind `gen` sits up to 3 values BEHIND `draws`
+        const bool want = active && (int32_t)(s.gen - s.draws) < (int32_t)need;
+        if (__ballot(want) == 0ull) break;
+        if (want) {
+            float v[4];
+            sampler_set(tab, s.index, s.gen >> 2, s.scramble, v);
+            const uint32_t slot = s.gen & (IRIS_RING_SLOTS - 1u);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) ring[(slot + k) * IRIS_BLOCK] = v[k];
+            s.gen += 4u;
+        }
     }
-    Refill r = sampler_refill(tab, s.index, s.dimension, s.scramble);
-    s.dimension += 1u;
-    s.in_buffer = 3u;
-    s.q0 = r.q0; s.q1 = r.q1; s.q2 = r.q2;
-    return r.first;
+}
+// After a path state has been moved to another lane (pool kernels): the set in progress is generated again
+// (ensure_draws then starts from the set that holds value `draws`; at most 3 + 12 < 16 ring slots are live).
+IRIS_DEV void sampler_rewind(Sampler &s) { s.gen = s.draws & ~3u; }
+IRIS_DEV float gen_0_1(DrawRing ring, Sampler &s) {  // sampler.rs:23-50; the caller has run ensure_draws
+    float r = ring[(s.draws & (IRIS_RING_SLOTS - 1u)) * IRIS_BLOCK];
+    s.draws++;
+    return r;
 }
 IRIS_DEV float gen_golden_ratio(const Sampler &s) {  // sampler.rs:65-71 (u32::MAX as f32 == 2^32)
     uint32_t u = (s.index + s.scramble) * 2654435769u;
@@ -454,9 +465,9 @@ IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool activ
 }
 
 // ---------------------------------------------------------------- sphere light (shape/sphere.rs:77-162)
-IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, SobolLds tab, Sampler &smp, V3 &p_out, float &pdf_out) {
-    float u0 = gen_0_1(tab, smp);
-    float u1 = gen_0_1(tab, smp);
+IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &smp, V3 &p_out, float &pdf_out) {
+    float u0 = gen_0_1(ring, smp);
+    float u1 = gen_0_1(ring, smp);
     V3 position = v3(sp.x, sp.y, sp.z);
     float radius = sp.w;
     V3 point = hit.back_face ? offset_origin(hit.point, -hit.normal) : offset_origin(hit.point, hit.normal);
@@ -518,13 +529,13 @@ IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &
 }
 
 // ---------------------------------------------------------------- GGX (sampling/ggx.rs)
-IRIS_DEV V3 ggx_sample(V3 wo_in, float ax, float ay, SobolLds tab, Sampler &smp) {  // ggx.rs:7-33
+IRIS_DEV V3 ggx_sample(V3 wo_in, float ax, float ay, DrawRing ring, Sampler &smp) {  // ggx.rs:7-33
     V3 wo = normalize(v3(ax * wo_in.x, ay * wo_in.y, wo_in.z));
     float len_2 = wo.x * wo.x + wo.y * wo.y;
     V3 t1_v = len_2 > 0.0f ? v3(-wo.y, wo.x, 0.0f) / rsqrt_exact(len_2) : v3(1.0f, 0.0f, 0.0f);
     V3 t2_v = cross(wo, t1_v);
-    float r = rsqrt_exact(gen_0_1(tab, smp));
-    float phi = 2.0f * PI_F * gen_0_1(tab, smp);
+    float r = rsqrt_exact(gen_0_1(ring, smp));
+    float phi = 2.0f * PI_F * gen_0_1(ring, smp);
     float sphi, cphi;
     iris_sincos(phi, sphi, cphi);
     float t1 = r * cphi;
@@ -585,20 +596,20 @@ IRIS_DEV F4 bsdf_pdf(const iris_bsdf &b, V3 wi, V3 wo) {
     }
     return splat(0.0f);  // specular.rs:35-37, fresnel.rs:46-48
 }
-IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, SobolLds tab, Sampler &smp, V3 &wi_out, F4 &val_out, F4 &pdf_out) {
+IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, DrawRing ring, Sampler &smp, V3 &wi_out, F4 &val_out, F4 &pdf_out) {
     wi_out = v3(0.0f, 0.0f, 0.0f);
     val_out = splat(0.0f);
     pdf_out = splat(0.0f);
     if (b.kind == IRIS_BSDF_LAMBERTIAN) {  // lambertian.rs:37-50
-        float r1 = gen_0_1(tab, smp);
-        float r2 = gen_0_1(tab, smp);
+        float r1 = gen_0_1(ring, smp);
+        float r2 = gen_0_1(ring, smp);
         V3 wi = cosine_unit_hemisphere(r1, r2);
         wi = same_hemisphere(wo, wi) ? wi : -wi;
         wi_out = wi;
         val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl) / PI_F;
         pdf_out = splat(fabs_(cos_theta(wi)) / PI_F);
     } else if (b.kind == IRIS_BSDF_MICROFACET) {  // microfacet.rs:65-88
-        V3 wh = ggx_sample(wo, b.p0, b.p1, tab, smp);
+        V3 wh = ggx_sample(wo, b.p0, b.p1, ring, smp);
         V3 wi = reflect(wo, wh);
         if (!(cos_theta(wo) == 0.0f || dot(wo, wh) < 0.0f || !same_hemisphere(wo, wi))) {
             float pdf = ggx_pdf(wo, wh, b.p0, b.p1) / (4.0f * dot(wo, wh));
@@ -617,7 +628,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         F4 fr;
 #pragma unroll
         for (int k = 0; k < 4; k++) fr.v[k] = fresnel_dielectric(cos_theta(wo), eta_a, eta_b.v[k]);
-        if (gen_0_1(tab, smp) < hero(fr)) {
+        if (gen_0_1(ring, smp) < hero(fr)) {
             V3 wi = v3(-wo.x, -wo.y, wo.z);
             F4 bs = spectrum_evaluate(sc.spectra[b.spec_a], wl) / fabs_(cos_theta(wi));
             wi_out = wi;
@@ -654,14 +665,21 @@ struct PathState {
 struct CamDev { float px, py, pz; float m[16]; };
 struct FrameDev { uint32_t width, height, seed, max_depth, min_depth; };
 
-// tile.rs:134-157: the camera sample for (x, y, sample_index)
-IRIS_DEV void raygen(const CamDev &cam, const FrameDev &fr, SobolLds tab, uint32_t x, uint32_t y, uint32_t sample_index, PathState &ps) {
+// tile.rs:134-157: the camera sample for (x, y, sample_index).  It consumes the first two values of set 0
+// (sampler.rs:23-50); the other two (u2, u3) are what the first bounce draws next.
+struct CamSample { uint32_t scramble; float hero_nm; V3 d; float u2, u3; };
+IRIS_DEV CamSample camera_sample(const CamDev &cam, const FrameDev &fr, SobolLds tab, uint32_t x, uint32_t y, uint32_t sample_index) {
+    CamSample cs;
     float cx = (((float)x + 0.5f) / (float)fr.width - 0.5f) * 2.0f;
     float cy = (((float)y + 0.5f) / (float)fr.height - 0.5f) * -2.0f;
-    ps.smp = sampler_new(x, y, sample_index, fr.seed);
-    ps.hero_nm = gen_golden_ratio(ps.smp) * LAMBDA_RANGE_NM + LAMBDA_MIN_NM;  // wavelength.rs:26-28
-    float j0 = 0.5f * gen_0_1(tab, ps.smp) / (float)fr.width;
-    float j1 = 0.5f * gen_0_1(tab, ps.smp) / (float)fr.height;
+    Sampler smp = sampler_new(x, y, sample_index, fr.seed);
+    cs.scramble = smp.scramble;
+    cs.hero_nm = gen_golden_ratio(smp) * LAMBDA_RANGE_NM + LAMBDA_MIN_NM;  // wavelength.rs:26-28
+    float u[4];
+    sampler_set(tab, sample_index, 0u, smp.scramble, u);
+    cs.u2 = u[2]; cs.u3 = u[3];
+    float j0 = 0.5f * u[0] / (float)fr.width;
+    float j1 = 0.5f * u[1] / (float)fr.height;
     float tx = cx + j0, ty = cy + j1, tz = 0.0f + 0.0f;
     const float *m = cam.m;  // matrix.rs:168-196
     float w = m[12] * tx + m[13] * ty + m[14] * tz + m[15];
@@ -669,11 +687,25 @@ IRIS_DEV void raygen(const CamDev &cam, const FrameDev &fr, SobolLds tab, uint32
                    (m[4] * tx + m[5] * ty + m[6] * tz + m[7]) / w,
                    (m[8] * tx + m[9] * ty + m[10] * tz + m[11]) / w);
     V3 origin = v3(cam.px, cam.py, cam.pz);
-    ps.ray = ray_new(origin, target - origin);
+    cs.d = ray_new(origin, target - origin).d;
+    return cs;
+}
+// Starts the path of a camera sample in `ps`; the unread half of set 0 goes to the lane's ring.
+IRIS_DEV void path_begin(const CamDev &cam, const CamSample &cs, uint32_t sample_index, DrawRing ring, PathState &ps) {
+    ps.smp.scramble = cs.scramble; ps.smp.index = sample_index; ps.smp.draws = 2u; ps.smp.gen = 4u;
+    ring[2 * IRIS_BLOCK] = cs.u2;
+    ring[3 * IRIS_BLOCK] = cs.u3;
+    ps.hero_nm = cs.hero_nm;
+    ps.ray.o = v3(cam.px, cam.py, cam.pz);
+    ps.ray.d = cs.d;
     ps.thr = splat(1.0f);
     ps.ppdf = splat(1.0f);
     ps.rad = splat(0.0f);
     ps.bounce = 0u;
+}
+IRIS_DEV void raygen(const CamDev &cam, const FrameDev &fr, SobolLds tab, DrawRing ring, uint32_t x, uint32_t y, uint32_t sample_index, PathState &ps) {
+    CamSample cs = camera_sample(cam, fr, tab, x, y, sample_index);
+    path_begin(cam, cs, sample_index, ring, ps);
 }
 
 // What `radiance` returns for a finished path, as XYZ (tile.rs:159-162)
@@ -690,10 +722,13 @@ IRIS_DEV V3 path_xyz(const PathState &ps) {
 // Every thread of the workgroup must call it (active=false for idle threads): the shadow scans
 // stage the sphere list cooperatively.
 template <int INTEG>
-IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, bool active,
+IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, DrawRing ring, bool active,
                            PathState &ps, int prim, float t, Counters &cnt) {
     constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
     constexpr bool NAIVE = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_SWSS_NAIVE);
+    // all draws of this bounce, generated for the whole wave at once: light pick 1 + light point 2 + BSDF 2 + BSDF 2 +
+    // roulette 1 with next-event estimation, BSDF 2 + roulette 1 without
+    ensure_draws(tab, ring, ps.smp, NAIVE ? 8u : 3u, active);
     bool alive = active;
     Hit hit = {};
     F4 wl = splat(LAMBDA_MIN_NM);
@@ -734,14 +769,15 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         bool want1 = false;
         if (alive) {
             // scene.rs:168-172 + sampler.rs:52-60
-            float u = gen_0_1(tab, ps.smp);
+            float u = gen_0_1(ring, ps.smp);
             uint32_t light_idx = f_as_index(u * (((float)sc.n_lights - 0.5f) - 0.0f) + 0.0f);
+            if (light_idx >= sc.n_lights) light_idx = sc.n_lights - 1u;  // never taken for u in [0, 1); keeps a bad draw from indexing out of bounds
             iris_light l = sc.lights[light_idx];
             light_prim = (int)l.prim;
             light_pick_weight = (float)sc.n_lights;
             light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl);
             light_sphere = sc.spheres[light_prim];
-            sphere_sample(light_sphere, hit, tab, ps.smp, light_pos, light_pdf);
+            sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf);
             shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
             bool facing_forward = dot(light_pos - hit.point, hit.normal) > 0.0f;
             want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
@@ -769,7 +805,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         float bs_cos = 0.0f;
         if (alive) {
             V3 wi;
-            bsdf_sample(sc, bsdf, shading_wo, wl, tab, ps.smp, wi, bs_values, bs_pdfs);
+            bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, wi, bs_values, bs_pdfs);
             bs_cos = fabs_(cos_theta(wi));
             shadow2 = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
             want2 = hero(bs_pdfs) > 0.0f;
@@ -793,7 +829,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         // hwss_naive.rs:64-88
         V3 wi;
         F4 bsdf_values, bsdf_pdfs;
-        bsdf_sample(sc, bsdf, shading_wo, wl, tab, ps.smp, wi, bsdf_values, bsdf_pdfs);
+        bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, wi, bsdf_values, bsdf_pdfs);
         float cos_t = fabs_(cos_theta(wi));
         if (hero(bsdf_pdfs) == 0.0f || cos_t == 0.0f) {
             alive = false;
@@ -802,7 +838,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             if (HWSS) ps.ppdf = ps.ppdf * bsdf_pdfs;
             if (ps.bounce >= fr.min_depth) {
                 float p = rmin(sum(ps.thr), 0.95f);
-                if (gen_0_1(tab, ps.smp) > p) alive = false;
+                if (gen_0_1(ring, ps.smp) > p) alive = false;
                 else ps.thr = ps.thr / splat(p);
             }
             if (alive) {

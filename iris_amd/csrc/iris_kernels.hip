@@ -37,6 +37,7 @@ using namespace iris;
 namespace {
 
 constexpr int BLOCK = 256;
+static_assert(BLOCK == IRIS_BLOCK, "the draw ring stride is the workgroup size");
 constexpr uint32_t STATE_ALIVE = 0x80000000u;
 
 struct Pool {
@@ -45,8 +46,7 @@ struct Pool {
     float4 *thr;   // throughput, 4 wavelengths
     float4 *ppdf;  // path pdfs, 4 wavelengths
     float4 *rad;   // radiance, 4 wavelengths
-    uint4 *smp;    // sampler: q0, q1, q2 (f32 bits), dimension | in_buffer << 16
-    uint4 *meta;   // scramble, sample index, item id, unused
+    uint4 *meta;   // sampler scramble, sample index, item id, sampler draws consumed
     uint2 *hit;    // closest hit of stage A: primitive, t (f32 bits)
 };
 
@@ -67,7 +67,6 @@ struct WfArgs {
     uint32_t items_per_block;
     uint32_t slots_per_block;
     uint32_t sphere_cap;      // LDS window, in spheres
-    uint32_t shade_threshold; // register-resident kernel: lanes holding a hit before a shade phase runs
 };
 
 struct BlockShared {
@@ -125,7 +124,7 @@ __device__ __forceinline__ unsigned long long item_of(const WfArgs &a, uint32_t 
 
 // ---- stage A: refill dead slots, generate camera rays, closest hit, compact hits into the queue ----
 template <int INTEG>
-__device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereStage &st, SobolLds tab, BlockShared &bs, Counters &cnt) {
+__device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereStage &st, SobolLds tab, DrawRing ring, BlockShared &bs, Counters &cnt) {
     const uint32_t slot0 = blockIdx.x * a.slots_per_block;
     for (uint32_t tile = 0; tile < a.slots_per_block; tile += BLOCK) {
         const uint32_t slot = slot0 + tile + threadIdx.x;
@@ -143,7 +142,7 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
             uint32_t pix = item - s_local * a.npix;
             uint32_t y = pix / a.fr.width;
             uint32_t x = pix - y * a.fr.width;
-            raygen(a.cam, a.fr, tab, x, y, a.s_begin + s_local, ps);
+            raygen(a.cam, a.fr, tab, ring, x, y, a.s_begin + s_local, ps);
             cnt.samples++;
         } else if (was_alive) {
             float4 ro = a.pool.rayo[slot];
@@ -179,9 +178,7 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
                 a.pool.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
                 if (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW) a.pool.ppdf[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
                 a.pool.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                a.pool.smp[slot] = make_uint4(__float_as_uint(ps.smp.q0), __float_as_uint(ps.smp.q1), __float_as_uint(ps.smp.q2),
-                                              ps.smp.dimension | (ps.smp.in_buffer << 16));
-                a.pool.meta[slot] = make_uint4(ps.smp.scramble, ps.smp.index, item, 0u);
+                a.pool.meta[slot] = make_uint4(ps.smp.scramble, ps.smp.index, item, ps.smp.draws);
             }
             a.pool.hit[slot] = make_uint2((uint32_t)prim, __float_as_uint(t));
             a.queue[slot0 + qi] = slot;
@@ -191,7 +188,7 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
 
 // ---- stage B: shade every queued hit ----
 template <int INTEG>
-__device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &st, SobolLds tab, uint32_t qn, Counters &cnt) {
+__device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &st, SobolLds tab, DrawRing ring, uint32_t qn, Counters &cnt) {
     constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
     const uint32_t slot0 = blockIdx.x * a.slots_per_block;
     for (uint32_t base = 0; base < qn; base += BLOCK) {
@@ -204,7 +201,7 @@ __device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &
         if (active) {
             slot = a.queue[slot0 + i];
             float4 ro = a.pool.rayo[slot], rd = a.pool.rayd[slot], th = a.pool.thr[slot], ra = a.pool.rad[slot];
-            uint4 sm = a.pool.smp[slot], me = a.pool.meta[slot];
+            uint4 me = a.pool.meta[slot];
             uint2 h = a.pool.hit[slot];
             ps.ray.o = v3(ro.x, ro.y, ro.z);
             ps.ray.d = v3(rd.x, rd.y, rd.z);
@@ -214,9 +211,8 @@ __device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &
             if (HWSS) { float4 pp = a.pool.ppdf[slot]; ps.ppdf = f4(pp.x, pp.y, pp.z, pp.w); }
             else ps.ppdf = splat(1.0f);
             ps.rad = f4(ra.x, ra.y, ra.z, ra.w);
-            ps.smp.q0 = __uint_as_float(sm.x); ps.smp.q1 = __uint_as_float(sm.y); ps.smp.q2 = __uint_as_float(sm.z);
-            ps.smp.dimension = sm.w & 0xffffu; ps.smp.in_buffer = sm.w >> 16;
-            ps.smp.scramble = me.x; ps.smp.index = me.y; ps.smp.draws = 0u;
+            ps.smp.scramble = me.x; ps.smp.index = me.y; ps.smp.draws = me.w;
+            sampler_rewind(ps.smp);  // the ring of this lane holds another path's values
             item = me.z;
             prim = (int)h.x;
             t = __uint_as_float(h.y);
@@ -225,7 +221,7 @@ __device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &
             ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
             ps.smp = sampler_new(0u, 0u, 0u, 0u);
         }
-        const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, tab, active, ps, prim, t, cnt);
+        const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, tab, ring, active, ps, prim, t, cnt);
         if (active) {
             if (cont) {
                 a.pool.rayo[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.hero_nm);
@@ -233,8 +229,7 @@ __device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &
                 a.pool.thr[slot] = make_float4(ps.thr.v[0], ps.thr.v[1], ps.thr.v[2], ps.thr.v[3]);
                 if (HWSS) a.pool.ppdf[slot] = make_float4(ps.ppdf.v[0], ps.ppdf.v[1], ps.ppdf.v[2], ps.ppdf.v[3]);
                 a.pool.rad[slot] = make_float4(ps.rad.v[0], ps.rad.v[1], ps.rad.v[2], ps.rad.v[3]);
-                a.pool.smp[slot] = make_uint4(__float_as_uint(ps.smp.q0), __float_as_uint(ps.smp.q1), __float_as_uint(ps.smp.q2),
-                                              ps.smp.dimension | (ps.smp.in_buffer << 16));
+                a.pool.meta[slot] = make_uint4(ps.smp.scramble, ps.smp.index, item, ps.smp.draws);
             } else {
                 store_result(a, item, path_xyz<INTEG>(ps));
                 a.pool.rayd[slot] = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(0u));
@@ -263,8 +258,10 @@ template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS_WAVES_PER_EU, IRIS_WAVES_PER_EU))) k_wavefront(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ BlockShared bs;
     stage_tables(sobol_lds);
+    DrawRing ring = ring_lds + threadIdx.x;
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
     if (threadIdx.x == 0) {
         block_range(a, bs.cursor, bs.w_end);
@@ -275,12 +272,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS
     __syncthreads();
     Counters cnt = {0u, 0u, 0u, 0u};
     for (;;) {
-        stage_gen_extend<INTEG>(a, st, sobol_lds, bs, cnt);
+        stage_gen_extend<INTEG>(a, st, sobol_lds, ring, bs, cnt);
         __syncthreads();
         const uint32_t qn = bs.qn;
         const bool more = bs.cursor < bs.w_end;
         if (qn == 0u && !more) break;
-        stage_shade<INTEG>(a, st, sobol_lds, qn, cnt);
+        stage_shade<INTEG>(a, st, sobol_lds, ring, qn, cnt);
         __syncthreads();
         if (threadIdx.x == 0) bs.qn = 0u;
         __syncthreads();
@@ -290,22 +287,32 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS
 
 
 // ---- the register-resident variant for sphere lists that fit the LDS window ----
-// Same per-lane device code, but the path state never leaves the registers: every lane owns one path,
-// there is no pool, no queue and no workgroup barrier in the loop, so waves run independently.  A wave
-// alternates between two wave-uniform phases, chosen by a ballot of the lane states:
-//   gen/extend: dead lanes take the next items of the workgroup's list (ballot + prefix sum + one LDS
-//               atomic per wave) and generate their camera ray; every lane holding a ray intersects it;
-//   shade:      run once at least `shade_threshold` lanes hold a hit (or nothing else can make progress).
-// Repeating the cheap gen/extend phase until most lanes hold a hit is what keeps the expensive shade
-// phase well filled without moving any state between lanes.
+// Same per-lane device code, but the state of a path never leaves the registers of the lane that shades
+// it: there is no pool in HBM and no workgroup barrier in the loop, so waves run independently.  What
+// keeps the lanes busy is a queue of PRIMARY HITS per wave in LDS:
+//   generate:  all 64 lanes take the next 64 camera samples of the workgroup's list, generate the camera
+//              ray and intersect it.  Misses are finished on the spot (their radiance is exactly zero);
+//              hits are compacted (ballot + prefix sum) into the wave's queue as an 11-dword record.
+//              Runs whenever fewer than 64 records are queued, always with a full wave.
+//   extend:    lanes whose path survived the last bounce intersect their new ray.
+//   refill:    lanes without a path pop a record each and become the first bounce of that path.
+//   shade:     every lane that holds a hit shades one bounce.
+// The expensive shade phase therefore runs with (nearly) every lane busy as long as work is left, and the
+// camera-sample code never runs for a handful of lanes.  No other wave touches a wave's queue, so no
+// synchronisation is needed.
 enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u };
+constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
+constexpr uint32_t PQ_CAP = 128;    // < 64 queued when a generate phase starts, <= 64 added by it
 
 template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
+    __shared__ uint32_t primq[BLOCK / 64][PQ_FIELDS][PQ_CAP];
     __shared__ BlockShared bs;
     stage_tables(sobol_lds);
+    DrawRing ring = ring_lds + threadIdx.x;
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
     st.resident = true;  // launched only when the whole list is in the window: no barrier inside the scans
     if (threadIdx.x == 0) {
@@ -314,6 +321,7 @@ __global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
     }
     __syncthreads();
     const uint32_t w_end = bs.w_end;
+    uint32_t(*q)[PQ_CAP] = primq[threadIdx.x / 64];
     Counters cnt = {0u, 0u, 0u, 0u};
     PathState ps;
     ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
@@ -322,194 +330,104 @@ __global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
     uint32_t lane_state = LANE_DEAD, item = 0u;
     int prim = -1;
     float t = 0.0f;
-    bool work_left = true;  // wave-uniform
-    for (;;) {
-        const uint32_t n_hit = (uint32_t)__popcll(__ballot(lane_state == LANE_HIT));
-        const uint32_t n_ray = (uint32_t)__popcll(__ballot(lane_state == LANE_RAY));
-        const uint32_t n_dead = 64u - n_hit - n_ray;
-        const bool can_extend = n_ray != 0u || (n_dead != 0u && work_left);
-        if (n_hit >= a.shade_threshold || !can_extend) {
-            if (n_hit == 0u) break;  // nothing in flight and nothing left to start
-            const bool active = lane_state == LANE_HIT;
-            const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, sobol_lds, active, ps, prim, t, cnt);
-            if (active) {
-                if (cont) {
-                    lane_state = LANE_RAY;
-                } else {
-                    store_result(a, item, path_xyz<INTEG>(ps));
-                    lane_state = LANE_DEAD;
-                }
-            }
-        } else {
-            if (work_left && n_dead != 0u) {
-                const bool need = lane_state == LANE_DEAD;
-                const uint32_t k = wave_reserve(need, &bs.cursor);
-                const unsigned long long id = item_of(a, k);
-                if (need && k < w_end && id < a.n_items) {
-                    item = (uint32_t)id;
-                    uint32_t s_local = item / a.npix;
-                    uint32_t pix = item - s_local * a.npix;
-                    uint32_t y = pix / a.fr.width;
-                    uint32_t x = pix - y * a.fr.width;
-                    raygen(a.cam, a.fr, sobol_lds, x, y, a.s_begin + s_local, ps);
-                    cnt.samples++;
-                    lane_state = LANE_RAY;
-                }
-                // the list is handed out in ascending k: once any lane was refused, it is exhausted
-                work_left = __ballot(need && k >= w_end) == 0ull;
-            }
-            const bool active = lane_state == LANE_RAY;
-            float t_new;
-            int prim_new;
-            scan_closest(a.sc, st, active, ps.ray, t_new, prim_new);
-            if (active) {  // lanes already holding a hit keep theirs
-                cnt.rays++;
-                cnt.sphere_tests += a.sc.n_prims;
-                t = t_new;
-                prim = prim_new;
-                if (prim >= 0) {
-                    lane_state = LANE_HIT;
-                } else {  // `None => break` (hwss_naive.rs:41-44)
-                    store_result(a, item, path_xyz<INTEG>(ps));
-                    lane_state = LANE_DEAD;
-                }
-            }
-        }
-    }
-    flush_counters(a, cnt);
-}
-
-
-// ---- register-resident kernel with a per-wave hit queue in LDS ----
-// As k_regwave, but a lane does not wait holding a hit: the gen/extend phase pushes every hit, with its
-// whole path state, into a ring queue in LDS that belongs to the wave (ballot + prefix sum give each
-// hit its entry; no other wave touches the queue, so there is no synchronisation at all), and frees the
-// lane for the next camera ray.  Once 64 hits are queued the wave pops them, one per free lane, and
-// shades with every lane busy.  Survivors keep their new ray in registers and are extended by the next
-// gen/extend phase.  The number of rays in flight in a wave is capped at the free queue entries, so the
-// queue cannot overflow.  96 entries per wave keep three workgroups per CU resident.
-constexpr uint32_t HITQ_FIELDS = 29;  // dwords of path state per queued hit
-constexpr uint32_t HITQ_CAP = 96;     // entries per wave
-
-#ifndef IRIS_REGQUEUE_WAVES
-#define IRIS_REGQUEUE_WAVES 2
-#endif
-template <int INTEG>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS_REGQUEUE_WAVES, IRIS_REGQUEUE_WAVES))) k_regqueue(WfArgs a) {
-    extern __shared__ float4 sphere_win[];
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
-    __shared__ BlockShared bs;
-    __shared__ uint32_t hitq[BLOCK / 64][HITQ_FIELDS][HITQ_CAP];
-    stage_tables(sobol_lds);
-    SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
-    st.resident = true;
-    if (threadIdx.x == 0) {
-        block_range(a, bs.cursor, bs.w_end);
-        bs.qn = 0u;
-    }
-    __syncthreads();
-    const uint32_t w_end = bs.w_end;
-    uint32_t(*q)[HITQ_CAP] = hitq[threadIdx.x / 64];
-    Counters cnt = {0u, 0u, 0u, 0u};
-    PathState ps;
-    ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
-    ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
-    ps.smp = sampler_new(0u, 0u, 0u, 0u);
-    uint32_t item = 0u;
-    bool has_ray = false;
     bool work_left = true;               // wave-uniform
     uint32_t q_head = 0u, q_count = 0u;  // wave-uniform
     for (;;) {
-        const unsigned long long ray_mask = __ballot(has_ray);
-        const uint32_t n_ray = (uint32_t)__popcll(ray_mask);
-        const uint32_t n_free = 64u - n_ray;
-        const bool can_extend = n_ray != 0u || work_left;
-        if ((q_count >= 64u && n_free != 0u) || !can_extend) {
-            if (q_count == 0u) break;
-            // ---- shade phase: pop hits into the lanes that hold no ray ----
-            const uint32_t n = q_count < n_free ? q_count : n_free;
-            const uint32_t rank = prefix_below(~ray_mask);
-            const bool active = !has_ray && rank < n;
-            int prim = 0;
-            float t = 0.0f;
-            if (active) {
-                const uint32_t e = (q_head + rank) % HITQ_CAP;
-                ps.ray.o = v3(__uint_as_float(q[0][e]), __uint_as_float(q[1][e]), __uint_as_float(q[2][e]));
-                ps.ray.d = v3(__uint_as_float(q[3][e]), __uint_as_float(q[4][e]), __uint_as_float(q[5][e]));
-                ps.hero_nm = __uint_as_float(q[6][e]);
-                ps.thr = f4(__uint_as_float(q[7][e]), __uint_as_float(q[8][e]), __uint_as_float(q[9][e]), __uint_as_float(q[10][e]));
-                ps.ppdf = f4(__uint_as_float(q[11][e]), __uint_as_float(q[12][e]), __uint_as_float(q[13][e]), __uint_as_float(q[14][e]));
-                ps.rad = f4(__uint_as_float(q[15][e]), __uint_as_float(q[16][e]), __uint_as_float(q[17][e]), __uint_as_float(q[18][e]));
-                ps.smp.q0 = __uint_as_float(q[19][e]); ps.smp.q1 = __uint_as_float(q[20][e]); ps.smp.q2 = __uint_as_float(q[21][e]);
-                ps.smp.dimension = q[22][e] & 0xffffu; ps.smp.in_buffer = q[22][e] >> 16;
-                ps.smp.scramble = q[23][e]; ps.smp.index = q[24][e]; ps.smp.draws = 0u;
-                ps.bounce = q[25][e];
-                item = q[26][e];
-                prim = (int)q[27][e];
-                t = __uint_as_float(q[28][e]);
-            }
-            q_head = (q_head + n) % HITQ_CAP;
-            q_count -= n;
-            const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, sobol_lds, active, ps, prim, t, cnt);
-            if (active) {
-                if (cont) has_ray = true;
-                else store_result(a, item, path_xyz<INTEG>(ps));
-            }
-        } else {
-            // ---- gen/extend phase: at most `room` rays in flight, so that their hits fit the queue ----
-            const uint32_t room = HITQ_CAP - q_count;
-            if (work_left && n_ray < room) {
-                const uint32_t rank = prefix_below(~ray_mask);
-                const bool need = !has_ray && rank < room - n_ray;
-                const uint32_t k = wave_reserve(need, &bs.cursor);
-                const unsigned long long id = item_of(a, k);
-                if (need && k < w_end && id < a.n_items) {
-                    item = (uint32_t)id;
-                    uint32_t s_local = item / a.npix;
-                    uint32_t pix = item - s_local * a.npix;
-                    uint32_t y = pix / a.fr.width;
-                    uint32_t x = pix - y * a.fr.width;
-                    raygen(a.cam, a.fr, sobol_lds, x, y, a.s_begin + s_local, ps);
-                    cnt.samples++;
-                    has_ray = true;
+        // ---- extend: the next ray of the paths that survived the last bounce ----
+        {
+            const bool active = lane_state == LANE_RAY;
+            if (__ballot(active) != 0ull) {
+                float t_new;
+                int prim_new;
+                scan_closest(a.sc, st, active, ps.ray, t_new, prim_new);
+                if (active) {
+                    cnt.rays++;
+                    cnt.sphere_tests += a.sc.n_prims;
+                    t = t_new;
+                    prim = prim_new;
+                    if (prim >= 0) {
+                        lane_state = LANE_HIT;
+                    } else {  // `None => break` (hwss_naive.rs:41-44)
+                        store_result(a, item, path_xyz<INTEG>(ps));
+                        lane_state = LANE_DEAD;
+                    }
                 }
-                work_left = __ballot(need && k >= w_end) == 0ull;
             }
-            // extend the first `room` rays of the wave (all of them, except in the rare case that more
-            // than `room` lanes survived the last shade phase)
-            const unsigned long long ray_mask2 = __ballot(has_ray);
-            const bool ext = has_ray && prefix_below(ray_mask2) < room;
-            float t;
-            int prim;
-            scan_closest(a.sc, st, ext, ps.ray, t, prim);
-            if (ext) {
+        }
+        // ---- generate: camera samples, 64 at a time, until a wave's worth of primary hits is queued ----
+        while (work_left && q_count < 64u) {
+            const uint32_t k = wave_reserve(true, &bs.cursor);
+            const unsigned long long id = item_of(a, k);
+            const bool valid = k < w_end && id < a.n_items;
+            work_left = __ballot(k >= w_end) == 0ull;  // the list is handed out in ascending k
+            CamSample cs = {};
+            Ray ray = {v3(a.cam.px, a.cam.py, a.cam.pz), v3(0.0f, 0.0f, 1.0f)};
+            uint32_t new_item = 0u, sample_index = 0u;
+            if (valid) {
+                new_item = (uint32_t)id;
+                uint32_t s_local = new_item / a.npix;
+                uint32_t pix = new_item - s_local * a.npix;
+                uint32_t y = pix / a.fr.width;
+                uint32_t x = pix - y * a.fr.width;
+                sample_index = a.s_begin + s_local;
+                cs = camera_sample(a.cam, a.fr, sobol_lds, x, y, sample_index);
+                ray.d = cs.d;
+                cnt.samples++;
+            }
+            float t_new;
+            int prim_new;
+            scan_closest(a.sc, st, valid, ray, t_new, prim_new);
+            if (valid) {
                 cnt.rays++;
                 cnt.sphere_tests += a.sc.n_prims;
-                if (prim < 0) store_result(a, item, path_xyz<INTEG>(ps));  // `None => break` (hwss_naive.rs:41-44)
+                if (prim_new < 0) store_result(a, new_item, v3(0.0f, 0.0f, 0.0f));  // radiance is exactly zero: `None => break`
             }
-            const bool hitp = ext && prim >= 0;
+            const bool hitp = valid && prim_new >= 0;
             const unsigned long long hmask = __ballot(hitp);
             if (hitp) {
-                const uint32_t e = (q_head + q_count + prefix_below(hmask)) % HITQ_CAP;
-                q[0][e] = __float_as_uint(ps.ray.o.x); q[1][e] = __float_as_uint(ps.ray.o.y); q[2][e] = __float_as_uint(ps.ray.o.z);
-                q[3][e] = __float_as_uint(ps.ray.d.x); q[4][e] = __float_as_uint(ps.ray.d.y); q[5][e] = __float_as_uint(ps.ray.d.z);
-                q[6][e] = __float_as_uint(ps.hero_nm);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    q[7 + k][e] = __float_as_uint(ps.thr.v[k]);
-                    q[11 + k][e] = __float_as_uint(ps.ppdf.v[k]);
-                    q[15 + k][e] = __float_as_uint(ps.rad.v[k]);
-                }
-                q[19][e] = __float_as_uint(ps.smp.q0); q[20][e] = __float_as_uint(ps.smp.q1); q[21][e] = __float_as_uint(ps.smp.q2);
-                q[22][e] = ps.smp.dimension | (ps.smp.in_buffer << 16);
-                q[23][e] = ps.smp.scramble; q[24][e] = ps.smp.index;
-                q[25][e] = ps.bounce;
-                q[26][e] = item;
-                q[27][e] = (uint32_t)prim;
-                q[28][e] = __float_as_uint(t);
+                const uint32_t e = (q_head + q_count + prefix_below(hmask)) % PQ_CAP;
+                q[0][e] = new_item; q[1][e] = sample_index; q[2][e] = cs.scramble; q[3][e] = __float_as_uint(cs.hero_nm);
+                q[4][e] = __float_as_uint(cs.d.x); q[5][e] = __float_as_uint(cs.d.y); q[6][e] = __float_as_uint(cs.d.z);
+                q[7][e] = __float_as_uint(t_new); q[8][e] = (uint32_t)prim_new;
+                q[9][e] = __float_as_uint(cs.u2); q[10][e] = __float_as_uint(cs.u3);
             }
             q_count += (uint32_t)__popcll(hmask);
-            if (ext) has_ray = false;  // queued as a hit or finished as a miss
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- refill: lanes without a path take a queued primary hit ----
+        {
+            const bool dead = lane_state == LANE_DEAD;
+            const unsigned long long dmask = __ballot(dead);
+            const uint32_t n_dead = (uint32_t)__popcll(dmask);
+            const uint32_t n = n_dead < q_count ? n_dead : q_count;
+            const uint32_t rank = prefix_below(dmask);
+            if (dead && rank < n) {
+                const uint32_t e = (q_head + rank) % PQ_CAP;
+                item = q[0][e];
+                CamSample cs;
+                cs.scramble = q[2][e]; cs.hero_nm = __uint_as_float(q[3][e]);
+                cs.d = v3(__uint_as_float(q[4][e]), __uint_as_float(q[5][e]), __uint_as_float(q[6][e]));
+                cs.u2 = __uint_as_float(q[9][e]); cs.u3 = __uint_as_float(q[10][e]);
+                path_begin(a.cam, cs, q[1][e], ring, ps);
+                t = __uint_as_float(q[7][e]);
+                prim = (int)q[8][e];
+                lane_state = LANE_HIT;
+            }
+            q_head = (q_head + n) % PQ_CAP;
+            q_count -= n;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- shade ----
+        const bool active = lane_state == LANE_HIT;
+        if (__ballot(active) == 0ull) break;  // nothing in flight, nothing queued, nothing left to generate
+        const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt);
+        if (active) {
+            if (cont) {
+                lane_state = LANE_RAY;
+            } else {
+                store_result(a, item, path_xyz<INTEG>(ps));
+                lane_state = LANE_DEAD;
+            }
         }
     }
     flush_counters(a, cnt);
@@ -530,8 +448,10 @@ template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) k_stage_gen_extend(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ BlockShared bs;
     stage_tables(sobol_lds);
+    DrawRing ring = ring_lds + threadIdx.x;
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
     if (threadIdx.x == 0) {
         uint32_t b;
@@ -541,7 +461,7 @@ __global__ void __launch_bounds__(BLOCK) k_stage_gen_extend(WfArgs a) {
     }
     __syncthreads();
     Counters cnt = {0u, 0u, 0u, 0u};
-    stage_gen_extend<INTEG>(a, st, sobol_lds, bs, cnt);
+    stage_gen_extend<INTEG>(a, st, sobol_lds, ring, bs, cnt);
     __syncthreads();
     if (threadIdx.x == 0) {
         a.blk_cursor[blockIdx.x] = bs.cursor < bs.w_end ? bs.cursor : bs.w_end;
@@ -554,13 +474,15 @@ template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) k_stage_shade(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     const uint32_t qn = a.blk_qn[blockIdx.x];
     if (qn == 0u) return;
+    DrawRing ring = ring_lds + threadIdx.x;
     stage_tables(sobol_lds);
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
     __syncthreads();
     Counters cnt = {0u, 0u, 0u, 0u};
-    stage_shade<INTEG>(a, st, sobol_lds, qn, cnt);
+    stage_shade<INTEG>(a, st, sobol_lds, ring, qn, cnt);
     flush_counters(a, cnt);
 }
 
@@ -587,12 +509,17 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const float4 *__restrict__ re
 // ---- stage-level debug kernels (parity tests) ----
 __global__ void __launch_bounds__(BLOCK) k_dbg_sampler(const uint32_t *xys, uint32_t n, uint32_t seed, uint32_t ndraws, float *out) {
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     stage_tables(sobol_lds);
     __syncthreads();
+    DrawRing ring = ring_lds + threadIdx.x;
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Sampler s = sampler_new(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], seed);
-    for (uint32_t k = 0; k < ndraws; k++) out[(size_t)i * ndraws + k] = gen_0_1(sobol_lds, s);
+    const bool active = i < n;
+    Sampler s = active ? sampler_new(xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], seed) : sampler_new(0u, 0u, 0u, 0u);
+    for (uint32_t k = 0; k < ndraws; k++) {  // uneven `need`s exercise every ring phase
+        ensure_draws(sobol_lds, ring, s, 1u + (k % 7u), active);
+        if (active) out[(size_t)i * ndraws + k] = gen_0_1(ring, s);
+    }
 }
 __global__ void __launch_bounds__(BLOCK) k_dbg_raygen(CamDev cam, FrameDev fr, const uint32_t *xys, uint32_t n, float *hero_out, float *o_out, float *d_out) {
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
@@ -600,12 +527,11 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_raygen(CamDev cam, FrameDev fr, c
     __syncthreads();
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    PathState ps;
-    raygen(cam, fr, sobol_lds, xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], ps);
-    F4 wl = wavelength_new(ps.hero_nm);
+    CamSample cs = camera_sample(cam, fr, sobol_lds, xys[3 * i], xys[3 * i + 1], xys[3 * i + 2]);
+    F4 wl = wavelength_new(cs.hero_nm);
     for (int k = 0; k < 4; k++) hero_out[4 * i + k] = wl.v[k];
-    o_out[3 * i] = ps.ray.o.x; o_out[3 * i + 1] = ps.ray.o.y; o_out[3 * i + 2] = ps.ray.o.z;
-    d_out[3 * i] = ps.ray.d.x; d_out[3 * i + 1] = ps.ray.d.y; d_out[3 * i + 2] = ps.ray.d.z;
+    o_out[3 * i] = cam.px; o_out[3 * i + 1] = cam.py; o_out[3 * i + 2] = cam.pz;
+    d_out[3 * i] = cs.d.x; d_out[3 * i + 1] = cs.d.y; d_out[3 * i + 2] = cs.d.z;
 }
 __global__ void __launch_bounds__(BLOCK) k_dbg_intersect(SceneDev sc, uint32_t cap, const float *o, const float *d, uint32_t n, int32_t *prim_out, float *t_out) {
     extern __shared__ float4 sphere_win[];
@@ -624,7 +550,9 @@ template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, FrameDev fr, uint32_t cap, const uint32_t *xys, uint32_t n, iris_trace *out) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     stage_tables(sobol_lds);
+    DrawRing ring = ring_lds + threadIdx.x;
     SphereStage st = stage_spheres(sc, sphere_win, cap);
     __syncthreads();
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -633,7 +561,7 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, Fr
     Counters cnt = {0u, 0u, 0u, 0u};
     iris_trace *tr = alive ? &out[i] : nullptr;
     if (alive) {
-        raygen(cam, fr, sobol_lds, xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], ps);
+        raygen(cam, fr, sobol_lds, ring, xys[3 * i], xys[3 * i + 1], xys[3 * i + 2], ps);
         F4 wl = wavelength_new(ps.hero_nm);
         for (int k = 0; k < 4; k++) tr->hero[k] = wl.v[k];
         tr->ray_o[0] = ps.ray.o.x; tr->ray_o[1] = ps.ray.o.y; tr->ray_o[2] = ps.ray.o.z;
@@ -654,7 +582,7 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, Fr
             if (n_hits < IRIS_TRACE_MAX_DEPTH) { tr->hit_prim[n_hits] = prim; tr->hit_t[n_hits] = t; }
             n_hits++;
         }
-        alive = shade_bounce<INTEG>(sc, st, fr, sobol_lds, alive, ps, prim, t, cnt);
+        alive = shade_bounce<INTEG>(sc, st, fr, sobol_lds, ring, alive, ps, prim, t, cnt);
     }
     if (tr) {
         V3 xyz = path_xyz<INTEG>(ps);
@@ -682,8 +610,6 @@ struct iris_ctx {
     int64_t result_bytes = 64ll << 30;
     int64_t multi_kernel = 0;
     int64_t mode = 0;             // 0 auto, 1 pool/queue kernels, 2 register-resident kernel
-    int64_t shade_threshold = 52;
-    int64_t reg_queue = 0;        // register-resident kernel: 1 = per-wave LDS hit queue variant (measured slower: DESIGN.md)
     int64_t reg_blocks_per_cu = 32;  // register-resident kernel: more workgroups than fit, for a short tail
     // scene
     bool have_scene = false;
@@ -728,7 +654,7 @@ void dev_free(void *p) {
 
 void free_pools(iris_ctx *c) {
     dev_free(c->pool.rayo); dev_free(c->pool.rayd); dev_free(c->pool.thr); dev_free(c->pool.ppdf); dev_free(c->pool.rad);
-    dev_free(c->pool.smp); dev_free(c->pool.meta); dev_free(c->pool.hit);
+    dev_free(c->pool.meta); dev_free(c->pool.hit);
     dev_free(c->d_queue); dev_free(c->d_blk_cursor); dev_free(c->d_blk_qn);
     c->pool = Pool{};
     c->d_queue = c->d_blk_cursor = c->d_blk_qn = nullptr;
@@ -745,7 +671,6 @@ int ensure_pools(iris_ctx *c, uint32_t blocks, uint32_t spb) {
     if ((rc = dev_alloc(c, &c->pool.thr, n))) return rc;
     if ((rc = dev_alloc(c, &c->pool.ppdf, n))) return rc;
     if ((rc = dev_alloc(c, &c->pool.rad, n))) return rc;
-    if ((rc = dev_alloc(c, &c->pool.smp, n))) return rc;
     if ((rc = dev_alloc(c, &c->pool.meta, n))) return rc;
     if ((rc = dev_alloc(c, &c->pool.hit, n))) return rc;
     if ((rc = dev_alloc(c, &c->d_queue, n))) return rc;
@@ -800,8 +725,7 @@ template <int INTEG>
 int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stream) {
     size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
     if (use_register_kernel(c)) {
-        if (c->reg_queue) hipLaunchKernelGGL(k_regqueue<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
-        else hipLaunchKernelGGL(k_regwave<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        hipLaunchKernelGGL(k_regwave<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
         HIP_TRY(c, hipGetLastError());
         c->stats.launches += 1;
         return IRIS_OK;
@@ -890,7 +814,6 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.items_per_block = ((a.n_items + blocks * 64u - 1) / (blocks * 64u)) * 64u;  // whole runs of 64
         a.slots_per_block = spb;
         a.sphere_cap = sphere_cap_for(c);
-        a.shade_threshold = (uint32_t)c->shade_threshold;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
         switch (p->integrator) {
         case IRIS_INT_HWSS_NAIVE: rc = launch_chunk<IRIS_INT_HWSS_NAIVE>(c, a, blocks, stream); break;
@@ -922,8 +845,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     c->stats.sphere_tests = h[3];
     c->stats.kernel_ms = trace_ms;
     c->stats.resolve_ms = resolve_ms;
-    c->stats.kernel = reg ? (c->reg_queue ? IRIS_KERNEL_REGISTER_QUEUE : IRIS_KERNEL_REGISTER)
-                          : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED);
+    c->stats.kernel = reg ? IRIS_KERNEL_REGISTER : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED);
     return IRIS_OK;
 }
 
@@ -988,11 +910,6 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "reg_blocks_per_cu") {
         if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "reg_blocks_per_cu out of range [1, 1024]");
         c->reg_blocks_per_cu = value;
-    } else if (k == "reg_queue") {
-        c->reg_queue = value ? 1 : 0;
-    } else if (k == "shade_threshold") {
-        if (value < 1 || value > 64) return fail(c, IRIS_E_ARG, "shade_threshold out of range [1, 64]");
-        c->shade_threshold = value;
     } else {
         return fail(c, IRIS_E_ARG, "unknown option " + k);
     }

@@ -64,7 +64,7 @@ class Stats(C.Structure):
                 ("kernel", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-KERNEL_NAMES = ("k_wavefront", "k_stage_gen_extend+k_stage_shade", "k_regwave", "k_regqueue")
+KERNEL_NAMES = ("k_wavefront", "k_stage_gen_extend+k_stage_shade", "k_regwave")
 
 
 class Trace(C.Structure):

@@ -207,8 +207,8 @@ def test_film_matches_committed_golden(gpu):
 
 def test_sample_ranges_and_schedules_do_not_change_the_film(gpu, iris_trig):
     """The result is a function of (pixel, sample index) only: chunking the sample range, the kernel
-    variant (pool/queue kernels, fused or as two kernels; register-resident kernel with and without the
-    LDS hit queue), the pool geometry and the scheduling thresholds leave every bit unchanged; spp_begin offsets select the same
+    variant (pool/queue kernels, fused or as two kernels; register-resident kernel), the pool geometry
+    and the grid size leave every bit unchanged; spp_begin offsets select the same
     streams the oracle selects; an empty range is a black film."""
     import iris_amd
     from iris_amd import Render, Scene
@@ -219,9 +219,8 @@ def test_sample_ranges_and_schedules_do_not_change_the_film(gpu, iris_trig):
     want, _ = oracle_film(iris_trig, flat, 96, 64, 12)
     assert np.array_equal(bits(base), bits(want))
     for opts in ({"result_bytes": 1 << 20}, {"multi_kernel": 1}, {"mode": 1, "blocks_per_cu": 1, "slots_per_block": 256},
-                 {"mode": 1, "blocks_per_cu": 8, "slots_per_block": 2048}, {"mode": 1}, {"mode": 2, "reg_queue": 0},
-                 {"mode": 2, "reg_queue": 1}, {"mode": 2, "shade_threshold": 1, "reg_blocks_per_cu": 1},
-                 {"mode": 2, "shade_threshold": 64, "reg_blocks_per_cu": 100}):
+                 {"mode": 1, "blocks_per_cu": 8, "slots_per_block": 2048}, {"mode": 1}, {"mode": 2},
+                 {"mode": 2, "reg_blocks_per_cu": 1}, {"mode": 2, "reg_blocks_per_cu": 100}):
         with iris_amd.HipWavefront(0, **opts) as g2:
             g2.upload(scene)
             film = g2.render_film(r)
