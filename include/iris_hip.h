@@ -166,6 +166,8 @@ const char *iris_last_error(const iris_ctx *ctx);
  *                     rays compacted before every scan); 2: register-resident kernel (needs the
  *                     sphere list to fit the LDS window)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 32)
+ *   "specialize"      1 (default): scenes with only Lambertian BSDFs over constant spectra (the reference's
+ *                     default scene) run kernels compiled for that class; 0: always the general kernels
  * None of them changes a single bit of the result.
  */
 int iris_ctx_set_option(iris_ctx *ctx, const char *key, int64_t value);

@@ -31,18 +31,18 @@ IRIS_DEV float rmax(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a
 IRIS_DEV float rmin(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
 // f32::clamp (NaN stays NaN)
 IRIS_DEV float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
-// Rust `as usize` on a value that is then used as a small index: saturating, NaN -> 0
+// Rust `as usize` on a value that is then used as a small index, and Rust `as i32`: saturating, NaN -> 0.
+// That is exactly what the gfx9 conversion instructions do in hardware (a C cast would be undefined
+// out of range, hence the explicit instruction).
 IRIS_DEV uint32_t f_as_index(float f) {
-    if (!(f > 0.0f)) return 0u;
-    if (f >= 4294967296.0f) return 0xffffffffu;
-    return (uint32_t)f;
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
-// Rust `as i32`: saturating, NaN -> 0
 IRIS_DEV int32_t f_as_i32(float f) {
-    if (f != f) return 0;
-    if (f >= 2147483648.0f) return 0x7fffffff;
-    if (f <= -2147483648.0f) return (int32_t)0x80000000;
-    return (int32_t)f;
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
 IRIS_DEV float rsqrt_exact(float x) { return __builtin_sqrtf(x); }  // correctly rounded (hipcc default for HIP)
 IRIS_DEV float fabs_(float x) { return __builtin_fabsf(x); }
@@ -169,13 +169,16 @@ IRIS_DEV float offset_component(float p, float n) {
 }
 IRIS_DEV V3 offset_origin(V3 p, V3 n) { return v3(offset_component(p.x, n.x), offset_component(p.y, n.y), offset_component(p.z, n.z)); }
 IRIS_DEV Ray ray_new(V3 o, V3 d) { Ray r = {o, normalize(d)}; return r; }  // ray.rs:14-19
+// offset_origin(p, flip ? -n : n): the reference's `if .. { offset_origin(p, -n) } else { offset_origin(p, n) }`
+// with the sign chosen first, so that the offset arithmetic runs once.
+IRIS_DEV V3 offset_origin_signed(V3 p, V3 n, bool flip) { return offset_origin(p, flip ? -n : n); }
 IRIS_DEV Ray ray_spawn(V3 o, V3 d, V3 normal) {                             // ray.rs:21-32
-    V3 o2 = dot(d, normal) < 0.0f ? offset_origin(o, -normal) : offset_origin(o, normal);
+    V3 o2 = offset_origin_signed(o, normal, dot(d, normal) < 0.0f);
     Ray r = {o2, normalize(d)};
     return r;
 }
 IRIS_DEV Ray ray_spawn_to(V3 o, V3 p, V3 normal) {  // ray.rs:34-45 (direction from the OFFSET origin)
-    V3 o2 = dot(p - o, normal) < 0.0f ? offset_origin(o, -normal) : offset_origin(o, normal);
+    V3 o2 = offset_origin_signed(o, normal, dot(p - o, normal) < 0.0f);
     Ray r = {o2, normalize(p - o2)};
     return r;
 }
@@ -357,7 +360,10 @@ IRIS_DEV float spectrum_evaluate_single(const iris_spectrum &s, float lambda) {
     float v = __builtin_fmaf(0.5f * x, y, 0.5f);
     return s.kind == IRIS_SPEC_UPSAMPLED ? v : s.hdr * v;
 }
-IRIS_DEV F4 spectrum_evaluate(const iris_spectrum &s, F4 wl) {  // spectrum/mod.rs:16-20
+// `mono` (a compile-time constant at every call site): the scene holds constant spectra only, so the four
+// wavelengths carry the same value and the compiler merges the four copies of every operation on them.
+IRIS_DEV F4 spectrum_evaluate(const iris_spectrum &s, F4 wl, bool mono) {  // spectrum/mod.rs:16-20
+    if (mono) return splat(s.c0);
     return f4(spectrum_evaluate_single(s, wl.v[0]), spectrum_evaluate_single(s, wl.v[1]),
               spectrum_evaluate_single(s, wl.v[2]), spectrum_evaluate_single(s, wl.v[3]));
 }
@@ -470,7 +476,7 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
     float u1 = gen_0_1(ring, smp);
     V3 position = v3(sp.x, sp.y, sp.z);
     float radius = sp.w;
-    V3 point = hit.back_face ? offset_origin(hit.point, -hit.normal) : offset_origin(hit.point, hit.normal);
+    V3 point = offset_origin_signed(hit.point, hit.normal, hit.back_face);
     if (distance_squared(position, point) <= radius * radius) {
         V3 light_normal = unit_sphere(u0, u1);
         V3 light_point = position + radius * light_normal;
@@ -509,7 +515,7 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
 IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &sphere_tests) {
     V3 position = v3(sp.x, sp.y, sp.z);
     float radius = sp.w;
-    V3 point = hit.back_face ? offset_origin(hit.point, -hit.normal) : offset_origin(hit.point, hit.normal);
+    V3 point = offset_origin_signed(hit.point, hit.normal, hit.back_face);
     if (distance_squared(position, point) <= radius * radius) {
         Ray ray = ray_spawn(hit.point, wi, hit.normal);
         sphere_tests++;
@@ -570,7 +576,7 @@ IRIS_DEV float ggx_pdf(V3 wo, V3 wh, float ax, float ay) {  // ggx.rs:61-64
 // ---------------------------------------------------------------- BSDFs (bsdf/*.rs)
 IRIS_DEV V3 reflect(V3 wo, V3 n) { return (-wo) + (2.0f * dot(wo, n)) * n; }  // microfacet.rs:91-93
 
-IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl) {  // microfacet.rs:33-57
+IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl, bool mono) {  // microfacet.rs:33-57
     float cos_theta_o = fabs_(cos_theta(wo));
     float cos_theta_i = fabs_(cos_theta(wi));
     V3 wh = wo + wi;
@@ -581,11 +587,11 @@ IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V
     float d = ggx_evaluate(wh, b.p0, b.p1);
     float f = fresnel_dielectric(dot(wi, wh_facing), 1.5f, 1.0f);
     float g = ggx_g(wo, wh, b.p0, b.p1);
-    return (((spectrum_evaluate(sc.spectra[b.spec_a], wl) * d) * g) * f) / (4.0f * cos_theta_o * cos_theta_i);
+    return (((spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) * d) * g) * f) / (4.0f * cos_theta_o * cos_theta_i);
 }
-IRIS_DEV F4 bsdf_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl) {
-    if (b.kind == IRIS_BSDF_LAMBERTIAN) return spectrum_evaluate(sc.spectra[b.spec_a], wl) / PI_F;  // lambertian.rs:24-31
-    if (b.kind == IRIS_BSDF_MICROFACET) return microfacet_evaluate(sc, b, wi, wo, wl);
+IRIS_DEV F4 bsdf_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl, bool mono) {
+    if (b.kind == IRIS_BSDF_LAMBERTIAN) return spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / PI_F;  // lambertian.rs:24-31
+    if (b.kind == IRIS_BSDF_MICROFACET) return microfacet_evaluate(sc, b, wi, wo, wl, mono);
     return splat(0.0f);  // specular.rs:26-33, fresnel.rs:37-44
 }
 IRIS_DEV F4 bsdf_pdf(const iris_bsdf &b, V3 wi, V3 wo) {
@@ -596,7 +602,7 @@ IRIS_DEV F4 bsdf_pdf(const iris_bsdf &b, V3 wi, V3 wo) {
     }
     return splat(0.0f);  // specular.rs:35-37, fresnel.rs:46-48
 }
-IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, DrawRing ring, Sampler &smp, V3 &wi_out, F4 &val_out, F4 &pdf_out) {
+IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, DrawRing ring, Sampler &smp, bool mono, V3 &wi_out, F4 &val_out, F4 &pdf_out) {
     wi_out = v3(0.0f, 0.0f, 0.0f);
     val_out = splat(0.0f);
     pdf_out = splat(0.0f);
@@ -606,7 +612,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         V3 wi = cosine_unit_hemisphere(r1, r2);
         wi = same_hemisphere(wo, wi) ? wi : -wi;
         wi_out = wi;
-        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl) / PI_F;
+        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / PI_F;
         pdf_out = splat(fabs_(cos_theta(wi)) / PI_F);
     } else if (b.kind == IRIS_BSDF_MICROFACET) {  // microfacet.rs:65-88
         V3 wh = ggx_sample(wo, b.p0, b.p1, ring, smp);
@@ -614,13 +620,13 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         if (!(cos_theta(wo) == 0.0f || dot(wo, wh) < 0.0f || !same_hemisphere(wo, wi))) {
             float pdf = ggx_pdf(wo, wh, b.p0, b.p1) / (4.0f * dot(wo, wh));
             wi_out = wi;
-            val_out = microfacet_evaluate(sc, b, wi, wo, wl);
+            val_out = microfacet_evaluate(sc, b, wi, wo, wl, mono);
             pdf_out = splat(pdf);
         }
     } else if (b.kind == IRIS_BSDF_SPECULAR) {  // specular.rs:39-49
         V3 wi = v3(-wo.x, -wo.y, wo.z);
         wi_out = wi;
-        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl) / fabs_(cos_theta(wi));
+        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / fabs_(cos_theta(wi));
         pdf_out = splat(1.0f);
     } else if (b.kind == IRIS_BSDF_FRESNEL) {  // fresnel.rs:30-34, 50-102
         const float eta_a = 1.0f;
@@ -630,7 +636,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         for (int k = 0; k < 4; k++) fr.v[k] = fresnel_dielectric(cos_theta(wo), eta_a, eta_b.v[k]);
         if (gen_0_1(ring, smp) < hero(fr)) {
             V3 wi = v3(-wo.x, -wo.y, wo.z);
-            F4 bs = spectrum_evaluate(sc.spectra[b.spec_a], wl) / fabs_(cos_theta(wi));
+            F4 bs = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / fabs_(cos_theta(wi));
             wi_out = wi;
             val_out = bs * fr;
             pdf_out = fr;
@@ -640,7 +646,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
             else { eta_i = hero(eta_b); eta_t = eta_a; }
             V3 wi;
             if (refract(wo, face_forward(v3(0.0f, 0.0f, 1.0f), wo), eta_i / eta_t, wi)) {
-                F4 ft = ((spectrum_evaluate(sc.spectra[b.spec_b], wl) * (1.0f - hero(fr))) * (eta_i * eta_i)) / (eta_t * eta_t);
+                F4 ft = ((spectrum_evaluate(sc.spectra[b.spec_b], wl, mono) * (1.0f - hero(fr))) * (eta_i * eta_i)) / (eta_t * eta_t);
                 float hero_value = hero(ft) / fabs_(cos_theta(wi));
                 wi_out = wi;
                 val_out = f4(hero_value, 0.0f, 0.0f, 0.0f);
@@ -721,7 +727,15 @@ IRIS_DEV V3 path_xyz(const PathState &ps) {
 // swss_slow.rs:45-78.  Returns true while the path continues (ps.ray is then the next ray).
 // Every thread of the workgroup must call it (active=false for idle threads): the shadow scans
 // stage the sphere list cooperatively.
-template <int INTEG>
+// CLS: scene class the kernel is compiled for (iris_scene_upload picks it):
+//   IRIS_CLS_GENERAL           every BSDF and spectrum kind;
+//   IRIS_CLS_LAMBERT_CONSTANT  only Lambertian BSDFs over constant spectra (the reference's default scene):
+//                              no other BSDF code is compiled in, and the four wavelengths of throughput,
+//                              pdfs and radiance are equal by construction, so each 4-wide operation is one.
+// Same operations in the same order on the same values either way: the film does not change by a bit.
+#define IRIS_CLS_GENERAL 0
+#define IRIS_CLS_LAMBERT_CONSTANT 1
+template <int INTEG, int CLS>
 IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, DrawRing ring, bool active,
                            PathState &ps, int prim, float t, Counters &cnt) {
     constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
@@ -729,6 +743,8 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
     // all draws of this bounce, generated for the whole wave at once: light pick 1 + light point 2 + BSDF 2 + BSDF 2 +
     // roulette 1 with next-event estimation, BSDF 2 + roulette 1 without
     ensure_draws(tab, ring, ps.smp, NAIVE ? 8u : 3u, active);
+    constexpr bool MONO = CLS == IRIS_CLS_LAMBERT_CONSTANT;
+    if (MONO) { ps.thr = splat(ps.thr.v[0]); ps.ppdf = splat(ps.ppdf.v[0]); ps.rad = splat(ps.rad.v[0]); }
     bool alive = active;
     Hit hit = {};
     F4 wl = splat(LAMBDA_MIN_NM);
@@ -740,19 +756,22 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         int2 info = sc.prim_info[prim];
         light_index = info.y;
         if (!NAIVE && light_index >= 0) {  // hwss_slow.rs:46-49, swss_slow.rs:45-48
-            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl);
+            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl, MONO);
             if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
             else ps.rad = ps.rad + ps.thr * le;
         }
         if (info.x < 0) alive = false;  // no material: break
-        else bsdf = sc.bsdfs[info.x];
+        else {
+            bsdf = sc.bsdfs[info.x];
+            if (CLS == IRIS_CLS_LAMBERT_CONSTANT) bsdf.kind = IRIS_BSDF_LAMBERTIAN;
+        }
     }
     if (alive) cnt.bounces++;
     V3 shading_wo = world_to_shading(hit, -ps.ray.d);
 
     if (NAIVE) {
         if (alive && ps.bounce == 0u && light_index >= 0) {  // hwss_naive.rs:51-58, swss_naive.rs:50-55
-            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl);
+            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl, MONO);
             if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
             else ps.rad = ps.rad + ps.thr * le;
         }
@@ -775,7 +794,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             iris_light l = sc.lights[light_idx];
             light_prim = (int)l.prim;
             light_pick_weight = (float)sc.n_lights;
-            light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl);
+            light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl, MONO);
             light_sphere = sc.spheres[light_prim];
             sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf);
             shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
@@ -791,7 +810,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
             if (st1 > target_t - IRIS_RAY_EPSILON) {
                 V3 shading_wi = world_to_shading(hit, shadow1.d);
-                F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl);
+                F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl, MONO);
                 F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
                 float cos_t = fabs_(cos_theta(shading_wi));
                 float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : light_pdf / (hero(bsdf_pdfs) + light_pdf);
@@ -805,7 +824,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         float bs_cos = 0.0f;
         if (alive) {
             V3 wi;
-            bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, wi, bs_values, bs_pdfs);
+            bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, MONO, wi, bs_values, bs_pdfs);
             bs_cos = fabs_(cos_theta(wi));
             shadow2 = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
             want2 = hero(bs_pdfs) > 0.0f;
@@ -829,7 +848,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         // hwss_naive.rs:64-88
         V3 wi;
         F4 bsdf_values, bsdf_pdfs;
-        bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, wi, bsdf_values, bsdf_pdfs);
+        bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, MONO, wi, bsdf_values, bsdf_pdfs);
         float cos_t = fabs_(cos_theta(wi));
         if (hero(bsdf_pdfs) == 0.0f || cos_t == 0.0f) {
             alive = false;

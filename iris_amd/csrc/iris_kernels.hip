@@ -187,7 +187,7 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
 }
 
 // ---- stage B: shade every queued hit ----
-template <int INTEG>
+template <int INTEG, int CLS>
 __device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &st, SobolLds tab, DrawRing ring, uint32_t qn, Counters &cnt) {
     constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
     const uint32_t slot0 = blockIdx.x * a.slots_per_block;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void stage_shade(const WfArgs &a, const SphereStage &
             ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
             ps.smp = sampler_new(0u, 0u, 0u, 0u);
         }
-        const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, tab, ring, active, ps, prim, t, cnt);
+        const bool cont = shade_bounce<INTEG, CLS>(a.sc, st, a.fr, tab, ring, active, ps, prim, t, cnt);
         if (active) {
             if (cont) {
                 a.pool.rayo[slot] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.hero_nm);
@@ -254,7 +254,7 @@ __device__ __forceinline__ unsigned long long item_of(const WfArgs &a, uint32_t 
 #ifndef IRIS_WAVES_PER_EU
 #define IRIS_WAVES_PER_EU 2
 #endif
-template <int INTEG>
+template <int INTEG, int CLS>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS_WAVES_PER_EU, IRIS_WAVES_PER_EU))) k_wavefront(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS
         const uint32_t qn = bs.qn;
         const bool more = bs.cursor < bs.w_end;
         if (qn == 0u && !more) break;
-        stage_shade<INTEG>(a, st, sobol_lds, ring, qn, cnt);
+        stage_shade<INTEG, CLS>(a, st, sobol_lds, ring, qn, cnt);
         __syncthreads();
         if (threadIdx.x == 0) bs.qn = 0u;
         __syncthreads();
@@ -304,7 +304,7 @@ enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u };
 constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
 constexpr uint32_t PQ_CAP = 128;    // < 64 queued when a generate phase starts, <= 64 added by it
 
-template <int INTEG>
+template <int INTEG, int CLS>
 __global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
         // ---- shade ----
         const bool active = lane_state == LANE_HIT;
         if (__ballot(active) == 0ull) break;  // nothing in flight, nothing queued, nothing left to generate
-        const bool cont = shade_bounce<INTEG>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt);
+        const bool cont = shade_bounce<INTEG, CLS>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt);
         if (active) {
             if (cont) {
                 lane_state = LANE_RAY;
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(BLOCK) k_stage_shade(WfArgs a) {
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
     __syncthreads();
     Counters cnt = {0u, 0u, 0u, 0u};
-    stage_shade<INTEG>(a, st, sobol_lds, ring, qn, cnt);
+    stage_shade<INTEG, IRIS_CLS_GENERAL>(a, st, sobol_lds, ring, qn, cnt);
     flush_counters(a, cnt);
 }
 
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, Fr
             if (n_hits < IRIS_TRACE_MAX_DEPTH) { tr->hit_prim[n_hits] = prim; tr->hit_t[n_hits] = t; }
             n_hits++;
         }
-        alive = shade_bounce<INTEG>(sc, st, fr, sobol_lds, ring, alive, ps, prim, t, cnt);
+        alive = shade_bounce<INTEG, IRIS_CLS_GENERAL>(sc, st, fr, sobol_lds, ring, alive, ps, prim, t, cnt);
     }
     if (tr) {
         V3 xyz = path_xyz<INTEG>(ps);
@@ -611,8 +611,11 @@ struct iris_ctx {
     int64_t multi_kernel = 0;
     int64_t mode = 0;             // 0 auto, 1 pool/queue kernels, 2 register-resident kernel
     int64_t reg_blocks_per_cu = 32;  // register-resident kernel: more workgroups than fit, for a short tail
+    int64_t specialize = 1;       // 1: use the kernel compiled for the scene's class; 0: always the general kernel
+    int scene_class = IRIS_CLS_GENERAL;
     // scene
     bool have_scene = false;
+    bool scene_is_lambert_constant = false;
     SceneDev sc = {};
     void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr;
     // pools
@@ -724,14 +727,17 @@ bool use_register_kernel(const iris_ctx *c) {
 template <int INTEG>
 int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stream) {
     size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
+    const bool lc = c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;
     if (use_register_kernel(c)) {
-        hipLaunchKernelGGL(k_regwave<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        if (lc) hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_LAMBERT_CONSTANT>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        else hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_GENERAL>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
         HIP_TRY(c, hipGetLastError());
         c->stats.launches += 1;
         return IRIS_OK;
     }
     if (!c->multi_kernel) {
-        hipLaunchKernelGGL(k_wavefront<INTEG>, dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        if (lc) hipLaunchKernelGGL((k_wavefront<INTEG, IRIS_CLS_LAMBERT_CONSTANT>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        else hipLaunchKernelGGL((k_wavefront<INTEG, IRIS_CLS_GENERAL>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
         HIP_TRY(c, hipGetLastError());
         c->stats.launches += 1;
         return IRIS_OK;
@@ -907,6 +913,9 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "mode") {
         if (value < 0 || value > 2) return fail(c, IRIS_E_ARG, "mode must be 0 (auto), 1 (pool) or 2 (register)");
         c->mode = value;
+    } else if (k == "specialize") {
+        c->specialize = value ? 1 : 0;
+        c->scene_class = (c->specialize && c->scene_is_lambert_constant) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL;
     } else if (k == "reg_blocks_per_cu") {
         if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "reg_blocks_per_cu out of range [1, 1024]");
         c->reg_blocks_per_cu = value;
@@ -962,6 +971,12 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     c->sc.lights = (const iris_light *)c->d_lights;
     c->sc.n_prims = s->n_prims;
     c->sc.n_lights = s->n_lights;
+    // scene class: only Lambertian BSDFs and only constant spectra -> the specialised kernels apply
+    bool lc = true;
+    for (uint32_t i = 0; i < s->n_bsdfs; i++) lc = lc && s->bsdfs[i].kind == IRIS_BSDF_LAMBERTIAN;
+    for (uint32_t i = 0; i < s->n_spectra; i++) lc = lc && s->spectra[i].kind == IRIS_SPEC_CONSTANT;
+    c->scene_is_lambert_constant = lc;
+    c->scene_class = (c->specialize && lc) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL;
     c->have_scene = true;
     return IRIS_OK;
 }

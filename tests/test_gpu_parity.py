@@ -219,7 +219,7 @@ def test_sample_ranges_and_schedules_do_not_change_the_film(gpu, iris_trig):
     want, _ = oracle_film(iris_trig, flat, 96, 64, 12)
     assert np.array_equal(bits(base), bits(want))
     for opts in ({"result_bytes": 1 << 20}, {"multi_kernel": 1}, {"mode": 1, "blocks_per_cu": 1, "slots_per_block": 256},
-                 {"mode": 1, "blocks_per_cu": 8, "slots_per_block": 2048}, {"mode": 1}, {"mode": 2},
+                 {"mode": 1, "blocks_per_cu": 8, "slots_per_block": 2048}, {"mode": 1}, {"mode": 2}, {"mode": 1, "specialize": 0}, {"mode": 2, "specialize": 0},
                  {"mode": 2, "reg_blocks_per_cu": 1}, {"mode": 2, "reg_blocks_per_cu": 100}):
         with iris_amd.HipWavefront(0, **opts) as g2:
             g2.upload(scene)
