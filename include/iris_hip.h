@@ -157,7 +157,7 @@ void iris_ctx_destroy(iris_ctx *ctx);
 const char *iris_last_error(const iris_ctx *ctx);
 
 /* Tuning knobs, all optional.  Keys:
- *   "blocks_per_cu"   persistent workgroups per CU (default 4)
+ *   "blocks_per_cu"   pool/queue kernels: persistent workgroups per CU (default 0 = as many as are resident at once)
  *   "slots_per_block" path-state slots per workgroup (default 1024)
  *   "result_bytes"    cap on the per-sample result buffer (default 64 GiB)
  *   "multi_kernel"    1: launch the two stages as separate kernels (for profiling);

@@ -403,11 +403,12 @@ IRIS_DEV V3 shading_to_world(const Hit &h, V3 s) {
               h.bitangeant.z * s.x + h.tangeant.z * s.y + h.normal.z * s.z);
 }
 
-// sphere.rs:26-35 + :53: the ray parameter of the first root > 0, or a negative number for None
+// sphere.rs:26-35 + :53: the ray parameter of the first root > 0, or a negative number for None.
+// `sp` is a staged sphere: (cx, cy, cz, radius * radius) -- the product the reference forms at sphere.rs:29.
 IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
     V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
     float half_b = dot(ray.d, oc);
-    float c = len_squared(oc) - sp.w * sp.w;
+    float c = len_squared(oc) - sp.w;
     float discrim = half_b * half_b - a * c;
     float t = -1.0f;
     if (discrim > 0.0f) {
@@ -418,6 +419,26 @@ IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
     }
     return t;
 }
+// The same test inside a closest-hit scan: `if t < closest_t && t > 0 { closest = .. }` (scene.rs:123-126).
+// Almost every test of a long list ends at `discrim > 0` being false, so the bookkeeping of the closest
+// hit lives inside that branch and the common path is the discriminant alone.
+IRIS_DEV void sphere_test(float4 sp, const Ray &ray, float a, int index, float &closest_t, int &closest) {
+    V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
+    float half_b = dot(ray.d, oc);
+    float c = len_squared(oc) - sp.w;
+    float discrim = half_b * half_b - a * c;
+    if (discrim > 0.0f) {
+        float root = rsqrt_exact(discrim);
+        float temp = (-half_b - root) / a;
+        if (!(temp > 0.0f)) temp = (-half_b + root) / a;
+        if (temp > 0.0f && temp < closest_t) { closest_t = temp; closest = index; }
+    }
+}
+IRIS_DEV float4 stage_sphere(float4 sp) { return make_float4(sp.x, sp.y, sp.z, sp.w * sp.w); }
+// Filler behind the last staged sphere (the scans read the window in batches): c = |oc|^2 + inf, so the
+// discriminant is -inf (or NaN) and the test can never report a hit.
+IRIS_DEV float4 stage_filler() { return make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff()); }
+#define IRIS_SCAN_PAD 8u
 // sphere.rs:36-40: the shading frame of a hit at parameter t (built once, for the winner only)
 IRIS_DEV Hit sphere_frame(float4 sp, const Ray &ray, float t) {
     Hit h;
@@ -433,9 +454,24 @@ IRIS_DEV Hit sphere_frame(float4 sp, const Ray &ray, float t) {
 // LDS window chunk by chunk by the whole workgroup.
 struct SphereStage {
     float4 *lds;           // window
-    uint32_t cap;          // window capacity in spheres
+    uint32_t cap;          // window capacity in spheres (a multiple of IRIS_SCAN_PAD)
     bool resident;         // n_prims <= cap and the window already holds the list
 };
+
+// One pass over `n` staged spheres (n real ones, followed by fillers up to a multiple of IRIS_SCAN_PAD),
+// B at a time: the B LDS reads of a batch are issued together, so their latency is paid once per batch.
+template <uint32_t B>
+IRIS_DEV void scan_window(const float4 *win, uint32_t n, uint32_t base, const Ray &ray, float a, float &closest_t, int &closest) {
+    for (uint32_t i = 0; i < n; i += B) {
+        float4 sp[B];
+#pragma unroll
+        for (uint32_t k = 0; k < B; k++) sp[k] = win[i + k];
+#pragma unroll
+        for (uint32_t k = 0; k < B; k++) {
+            sphere_test(sp[k], ray, a, (int)(base + i + k), closest_t, closest);
+        }
+    }
+}
 
 // Scene::intersection / ray_hits_point / ray_hits_object all reduce to this scan (scene.rs:116-166):
 // closest t > 0 over all primitives in index order, strict '<' so the lowest index wins ties.
@@ -446,24 +482,15 @@ IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool activ
     int closest = -1;
     float a = len_squared(ray.d);  // sphere.rs:27 (loop-invariant)
     if (st.resident) {
-        if (active) {
-            for (uint32_t i = 0; i < sc.n_prims; i++) {
-                float t = sphere_hit_t(st.lds[i], ray, a);
-                if (t > 0.0f && t < closest_t) { closest_t = t; closest = (int)i; }
-            }
-        }
+        if (active) scan_window<4>(st.lds, sc.n_prims, 0u, ray, a, closest_t, closest);
     } else {
         for (uint32_t base = 0; base < sc.n_prims; base += st.cap) {
             uint32_t n = sc.n_prims - base < st.cap ? sc.n_prims - base : st.cap;
+            uint32_t n_pad = (n + IRIS_SCAN_PAD - 1u) & ~(IRIS_SCAN_PAD - 1u);
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) st.lds[i] = sc.spheres[base + i];
+            for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) st.lds[i] = i < n ? stage_sphere(sc.spheres[base + i]) : stage_filler();
             __syncthreads();
-            if (active) {
-                for (uint32_t i = 0; i < n; i++) {
-                    float t = sphere_hit_t(st.lds[i], ray, a);
-                    if (t > 0.0f && t < closest_t) { closest_t = t; closest = (int)(base + i); }
-                }
-            }
+            if (active) scan_window<8>(st.lds, n, base, ray, a, closest_t, closest);
         }
     }
     t_out = closest_t;
@@ -519,7 +546,7 @@ IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &
     if (distance_squared(position, point) <= radius * radius) {
         Ray ray = ray_spawn(hit.point, wi, hit.normal);
         sphere_tests++;
-        float t = sphere_hit_t(sp, ray, len_squared(ray.d));
+        float t = sphere_hit_t(stage_sphere(sp), ray, len_squared(ray.d));
         if (t > 0.0f) {
             V3 lp = ray.o + ray.d * t;
             V3 ln = (lp - position) / radius;

@@ -100,8 +100,10 @@ __device__ __forceinline__ SphereStage stage_spheres(const SceneDev &sc, float4 
     st.lds = win;
     st.cap = cap;
     st.resident = sc.n_prims <= cap;
-    if (st.resident)
-        for (uint32_t i = threadIdx.x; i < sc.n_prims; i += blockDim.x) win[i] = sc.spheres[i];
+    if (st.resident) {
+        const uint32_t n_pad = (sc.n_prims + IRIS_SCAN_PAD - 1u) & ~(IRIS_SCAN_PAD - 1u);
+        for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) win[i] = i < sc.n_prims ? stage_sphere(sc.spheres[i]) : stage_filler();
+    }
     return st;
 }
 
@@ -251,11 +253,11 @@ __device__ __forceinline__ unsigned long long item_of(const WfArgs &a, uint32_t 
 }
 
 // ---- the persistent kernel: both stages in a loop, one workgroup = one independent wavefront tracer ----
-#ifndef IRIS_WAVES_PER_EU
-#define IRIS_WAVES_PER_EU 2
-#endif
+// Register budget: the Lambertian/constant-spectrum variant fits three waves per SIMD without spilling; the
+// general one (every BSDF compiled in) is held at two.
 template <int INTEG, int CLS>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS_WAVES_PER_EU, IRIS_WAVES_PER_EU))) k_wavefront(WfArgs a) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLS == IRIS_CLS_LAMBERT_CONSTANT ? 3 : 2)))
+k_wavefront(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
@@ -305,7 +307,7 @@ constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz
 constexpr uint32_t PQ_CAP = 128;    // < 64 queued when a generate phase starts, <= 64 added by it
 
 template <int INTEG, int CLS>
-__global__ void __launch_bounds__(BLOCK) k_regwave(WfArgs a) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_regwave(WfArgs a) {
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
@@ -605,7 +607,7 @@ struct iris_ctx {
     int n_cus = 0;
     std::string err;
     // options
-    int64_t blocks_per_cu = 4;
+    int64_t blocks_per_cu = 0;    // 0: as many persistent workgroups per CU as are resident at once (occupancy query)
     int64_t slots_per_block = 1024;
     int64_t result_bytes = 64ll << 30;
     int64_t multi_kernel = 0;
@@ -634,7 +636,7 @@ struct iris_ctx {
 
 namespace {
 
-constexpr uint32_t SPHERE_CAP = 2048;  // LDS window: 32 KiB of float4
+constexpr uint32_t SPHERE_CAP = 1024;  // LDS window: 16 KiB of float4 (three pool-kernel workgroups per CU stay resident)
 
 int fail(iris_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -712,7 +714,11 @@ FrameDev frame_dev(const iris_render_params *p) {
     FrameDev f = {p->width, p->height, p->seed, p->max_depth, p->min_depth};
     return f;
 }
-uint32_t sphere_cap_for(const iris_ctx *c) { return std::min<uint32_t>(std::max<uint32_t>(c->sc.n_prims, 1u), SPHERE_CAP); }
+// window capacity in spheres: the list rounded up to whole scan batches, at most SPHERE_CAP
+uint32_t sphere_cap_for(const iris_ctx *c) {
+    return std::min<uint32_t>((std::max<uint32_t>(c->sc.n_prims, 1u) + IRIS_SCAN_PAD - 1u) & ~(IRIS_SCAN_PAD - 1u), SPHERE_CAP);
+}
+static_assert(SPHERE_CAP % IRIS_SCAN_PAD == 0, "the LDS window holds whole scan batches");
 
 // The register-resident kernel needs the whole sphere list in the LDS window; it is the default for
 // short lists (where shading, not the scans, is the cost), the pool/queue kernels for long ones (where
@@ -722,6 +728,16 @@ bool use_register_kernel(const iris_ctx *c) {
     if (c->multi_kernel || c->mode == 1) return false;
     if (c->sc.n_prims > SPHERE_CAP) return false;
     return c->mode == 2 || c->sc.n_prims <= REGISTER_KERNEL_MAX_PRIMS;
+}
+
+// Workgroups of the fused pool/queue kernel that one CU holds at a time (registers, LDS).
+template <int INTEG>
+int pool_blocks_per_cu(const iris_ctx *c, size_t dyn_lds) {
+    int n = 0;
+    hipError_t e = c->scene_class == IRIS_CLS_LAMBERT_CONSTANT
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wavefront<INTEG, IRIS_CLS_LAMBERT_CONSTANT>, BLOCK, dyn_lds)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wavefront<INTEG, IRIS_CLS_GENERAL>, BLOCK, dyn_lds);
+    return (e == hipSuccess && n >= 1) ? n : 2;
 }
 
 template <int INTEG>
@@ -789,7 +805,17 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         c->film_cap = npix;
     }
     const bool reg = use_register_kernel(c);
-    uint32_t blocks = (uint32_t)(c->n_cus * (reg ? c->reg_blocks_per_cu : c->blocks_per_cu));
+    int64_t per_cu = reg ? c->reg_blocks_per_cu : c->blocks_per_cu;
+    if (per_cu == 0) {
+        const size_t dyn = (size_t)sphere_cap_for(c) * sizeof(float4);
+        switch (p->integrator) {
+        case IRIS_INT_HWSS_NAIVE: per_cu = pool_blocks_per_cu<IRIS_INT_HWSS_NAIVE>(c, dyn); break;
+        case IRIS_INT_HWSS_SLOW: per_cu = pool_blocks_per_cu<IRIS_INT_HWSS_SLOW>(c, dyn); break;
+        case IRIS_INT_SWSS_NAIVE: per_cu = pool_blocks_per_cu<IRIS_INT_SWSS_NAIVE>(c, dyn); break;
+        default: per_cu = pool_blocks_per_cu<IRIS_INT_SWSS_SLOW>(c, dyn); break;
+        }
+    }
+    uint32_t blocks = (uint32_t)(c->n_cus * per_cu);
     uint32_t spb = (uint32_t)c->slots_per_block;
     if (!reg && (rc = ensure_pools(c, blocks, spb))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), stream));
@@ -900,7 +926,7 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return IRIS_E_ARG;
     std::string k(key);
     if (k == "blocks_per_cu") {
-        if (value < 1 || value > 64) return fail(c, IRIS_E_ARG, "blocks_per_cu out of range [1, 64]");
+        if (value < 0 || value > 64) return fail(c, IRIS_E_ARG, "blocks_per_cu out of range [0, 64]");
         c->blocks_per_cu = value;
     } else if (k == "slots_per_block") {
         if (value < BLOCK || value > 65536 || value % BLOCK) return fail(c, IRIS_E_ARG, "slots_per_block must be a multiple of 256 in [256, 65536]");

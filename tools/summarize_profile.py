@@ -29,14 +29,14 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
         print("  %-46s VGPR %s accum %s SGPR %s LDS %s scratch %s grid %s wg %s" % (
             k[:46], row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"),
             row.get("Scratch_Size"), row.get("Grid_Size"), row.get("Workgroup_Size")))
-print("== PMC counters, summed over dispatches per kernel ==")
+print("== PMC counters per kernel: sum over all dispatches of all passes that collected the counter, and per dispatch ==")
 agg = defaultdict(lambda: defaultdict(float))
 ndisp = defaultdict(set)
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = short(row["Kernel_Name"])
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-        ndisp[(k, row["Counter_Name"])].add(row["Dispatch_Id"])
+        ndisp[(k, row["Counter_Name"])].add((f, row["Dispatch_Id"]))  # a counter may be collected in several passes
 for k, cs in agg.items():
     if not k.startswith("k_"):
         continue
