@@ -25,6 +25,11 @@ sys.path.insert(0, ROOT)
 # Algorithmic flop model (DESIGN.md "Roofline"): FMA = 2, sqrt/div/sin/cos = 1.
 F_CAM, F_ISECT, F_FRAME, F_SHADE = 120.0, 27.0, 44.0, 400.0
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (vector)"
+# HBM bytes per launch of the path-tracing kernel on the default workload, from the PMC passes of the same
+# command (profiles/r01_s1_configB_summary.txt: TCC_EA0_WRREQ_64B * 64 + other WRREQ * 32 + TCC_EA0_RDREQ * 64;
+# writes are 16-byte-per-lane streaming stores, which the counter reads exactly on gfx950).  It is the
+# per-sample result buffer: 16 B x 2.12e9 samples.
+MEASURED_TRAFFIC_DEFAULT_WORKLOAD = 3.54e10
 
 
 def algorithmic_flops(st):
@@ -117,6 +122,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    default_workload = (args.scene, args.width, args.height, args.spp) == ("s1", 1920, 1080, 1024) and not opts
     if rank == 0:
         samples_per_step = args.width * args.height * spp_total
         value = samples_per_step * args.steps / 1e6 / elapsed
@@ -132,7 +138,8 @@ def main():
                        "width": args.width, "height": args.height, "spp_per_gpu": args.spp, "parallelism": "spp-split x%d" % world},
             # rank 0's path-tracing kernel, timed with HIP events on its own stream inside the library
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                         "traffic": MEASURED_TRAFFIC_DEFAULT_WORKLOAD if default_workload else None,
                          "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / args.steps / max(1, st.chunks), 3),
                          "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters)"},
             "rays_per_s": round(st.rays / (kernel_ms / args.steps * 1e-3), 1) if kernel_ms else None,
