@@ -18,6 +18,7 @@
 
 #define IRIS_TABLE_QUAL __device__ const
 #include "tables/cie1931.inc"
+#include "tables/sobol_rev16.inc"
 #define IRIS_SOBOL_SETS 64u
 
 namespace iris {
@@ -227,22 +228,53 @@ IRIS_DEV uint32_t lk_scramble(uint32_t n, uint32_t seed) {
 }
 IRIS_DEV float unit_float_from_bits(uint32_t v) { return __uint_as_float((v >> 9) | 0x3f800000u) - 1.0f; }
 
-// Sobol direction vectors in LDS: sobol_lds[bit * 64 + set] = the four 16-bit reversed vectors of
-// (set, bit) packed as {d0 | d1 << 16, d2 | d3 << 16}.  Bit-major so that lanes sitting at different
-// dimension sets hit different banks.
+// Sobol direction vectors.  The XOR over the 16 index bits is done a nibble at a time from a table in
+// LDS: lut[(set * 4 + j) * 16 + v] = XOR of the vectors of bits 4j .. 4j+3 of `set` selected by the 4-bit
+// value v (its most significant bit selects bit 4j), the four 16-bit reversed vectors of a bit packed as
+// {d0 | d1 << 16, d2 | d3 << 16}.  The table covers the first IRIS_SOBOL_LUT_SETS sets (128 draws: every path
+// of 15 bounces); later sets read the direction vectors bit by bit from the constant table in global memory.
+// Lanes of a wave are at the same set and differ in v, i.e. they read different banks or the same address.
+#define IRIS_SOBOL_LUT_SETS 32u
+#define IRIS_SOBOL_LUT_ENTRIES (IRIS_SOBOL_LUT_SETS * 4u * 16u)
 typedef const uint2 *SobolLds;
+IRIS_DEV uint2 sobol_packed_vectors(uint32_t set, uint32_t bit) {
+    const unsigned short *v = IRIS_SOBOL_REV16[set][bit];
+    return make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
+}
+IRIS_DEV uint2 sobol_lut_entry(uint32_t e) {
+    const uint32_t set = e >> 6, j = (e >> 4) & 3u, v = e & 15u;
+    uint2 x = make_uint2(0u, 0u);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        if (v & (8u >> i)) {
+            uint2 d = sobol_packed_vectors(set, 4u * j + i);
+            x.x ^= d.x; x.y ^= d.y;
+        }
+    }
+    return x;
+}
 
 // This build's Owen-scrambled Sobol (docs/SPEC.md); stands where the reference calls the external
 // crate: sobol::sample_4d(index, dimension_set, seed), sampler.rs:30-34.
-IRIS_DEV void sobol_sample_4d(SobolLds tab, uint32_t index, uint32_t set, uint32_t seed, float out[4]) {
+IRIS_DEV void sobol_sample_4d(SobolLds lut, uint32_t index, uint32_t set, uint32_t seed, float out[4]) {
     uint32_t shuffled_rev = lk_scramble(__builtin_bitreverse32(index), lowbias32(seed));
     uint32_t x01 = 0u, x23 = 0u;
+    if (set < IRIS_SOBOL_LUT_SETS) {
 #pragma unroll
-    for (uint32_t b = 0; b < 16; b++) {
-        uint32_t m = (uint32_t)((int32_t)(shuffled_rev << b) >> 31);  // all ones iff bit (31-b) is set
-        uint2 v = tab[b * IRIS_SOBOL_SETS + set];
-        x01 ^= v.x & m;
-        x23 ^= v.y & m;
+        for (uint32_t j = 0; j < 4; j++) {
+            uint2 v = lut[(set * 4u + j) * 16u + ((shuffled_rev >> (28u - 4u * j)) & 15u)];
+            x01 ^= v.x;
+            x23 ^= v.y;
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t b = 0; b < 16; b++) {
+            if ((shuffled_rev << b) & 0x80000000u) {  // index bit b after the shuffle
+                uint2 v = sobol_packed_vectors(set, b);
+                x01 ^= v.x;
+                x23 ^= v.y;
+            }
+        }
     }
     uint32_t xr[4] = {x01 & 0xffffu, x01 >> 16, x23 & 0xffffu, x23 >> 16};
 #pragma unroll

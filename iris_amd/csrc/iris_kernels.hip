@@ -27,10 +27,6 @@
 
 #include "iris_device.h"
 
-#define IRIS_SOBOL_TABLE_QUAL __device__ const
-#undef IRIS_TABLE_QUAL
-#define IRIS_TABLE_QUAL __device__ const
-#include "tables/sobol_rev16.inc"
 
 using namespace iris;
 
@@ -89,11 +85,7 @@ __device__ __forceinline__ uint32_t wave_reserve(bool pred, uint32_t *lds_counte
 }
 
 __device__ __forceinline__ void stage_tables(uint2 *sobol_lds) {
-    for (uint32_t e = threadIdx.x; e < 16u * IRIS_SOBOL_SETS; e += blockDim.x) {
-        uint32_t b = e / IRIS_SOBOL_SETS, set = e % IRIS_SOBOL_SETS;
-        const unsigned short *v = IRIS_SOBOL_REV16[set][b];
-        sobol_lds[e] = make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
-    }
+    for (uint32_t e = threadIdx.x; e < IRIS_SOBOL_LUT_ENTRIES; e += blockDim.x) sobol_lds[e] = sobol_lut_entry(e);
 }
 __device__ __forceinline__ SphereStage stage_spheres(const SceneDev &sc, float4 *win, uint32_t cap) {
     SphereStage st;
@@ -259,7 +251,7 @@ template <int INTEG, int CLS>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLS == IRIS_CLS_LAMBERT_CONSTANT ? 3 : 2)))
 k_wavefront(WfArgs a) {
     extern __shared__ float4 sphere_win[];
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ BlockShared bs;
     stage_tables(sobol_lds);
@@ -295,7 +287,7 @@ k_wavefront(WfArgs a) {
 //   generate:  all 64 lanes take the next 64 camera samples of the workgroup's list, generate the camera
 //              ray and intersect it.  Misses are finished on the spot (their radiance is exactly zero);
 //              hits are compacted (ballot + prefix sum) into the wave's queue as an 11-dword record.
-//              Runs whenever fewer than 64 records are queued, always with a full wave.
+//              Runs whenever fewer than PQ_LOW records are queued, always with a full wave.
 //   extend:    lanes whose path survived the last bounce intersect their new ray.
 //   refill:    lanes without a path pop a record each and become the first bounce of that path.
 //   shade:     every lane that holds a hit shades one bounce.
@@ -304,12 +296,13 @@ k_wavefront(WfArgs a) {
 // synchronisation is needed.
 enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u };
 constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
-constexpr uint32_t PQ_CAP = 128;    // < 64 queued when a generate phase starts, <= 64 added by it
+constexpr uint32_t PQ_CAP = 104;    // < PQ_CAP - 63 queued when a generate phase starts, <= 64 added by it
+constexpr uint32_t PQ_LOW = PQ_CAP - 63;  // generate while fewer records than this are queued
 
 template <int INTEG, int CLS>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_regwave(WfArgs a) {
     extern __shared__ float4 sphere_win[];
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ uint32_t primq[BLOCK / 64][PQ_FIELDS][PQ_CAP];
     __shared__ BlockShared bs;
@@ -357,7 +350,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             }
         }
         // ---- generate: camera samples, 64 at a time, until a wave's worth of primary hits is queued ----
-        while (work_left && q_count < 64u) {
+        while (work_left && q_count < PQ_LOW) {
             const uint32_t k = wave_reserve(true, &bs.cursor);
             const unsigned long long id = item_of(a, k);
             const bool valid = k < w_end && id < a.n_items;
@@ -449,7 +442,7 @@ __global__ void __launch_bounds__(BLOCK) k_pool_init(WfArgs a) {
 template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) k_stage_gen_extend(WfArgs a) {
     extern __shared__ float4 sphere_win[];
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ BlockShared bs;
     stage_tables(sobol_lds);
@@ -475,7 +468,7 @@ __global__ void __launch_bounds__(BLOCK) k_stage_gen_extend(WfArgs a) {
 template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) k_stage_shade(WfArgs a) {
     extern __shared__ float4 sphere_win[];
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     const uint32_t qn = a.blk_qn[blockIdx.x];
     if (qn == 0u) return;
@@ -510,7 +503,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const float4 *__restrict__ re
 
 // ---- stage-level debug kernels (parity tests) ----
 __global__ void __launch_bounds__(BLOCK) k_dbg_sampler(const uint32_t *xys, uint32_t n, uint32_t seed, uint32_t ndraws, float *out) {
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     stage_tables(sobol_lds);
     __syncthreads();
@@ -524,7 +517,7 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_sampler(const uint32_t *xys, uint
     }
 }
 __global__ void __launch_bounds__(BLOCK) k_dbg_raygen(CamDev cam, FrameDev fr, const uint32_t *xys, uint32_t n, float *hero_out, float *o_out, float *d_out) {
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
     stage_tables(sobol_lds);
     __syncthreads();
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -551,7 +544,7 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_intersect(SceneDev sc, uint32_t c
 template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, FrameDev fr, uint32_t cap, const uint32_t *xys, uint32_t n, iris_trace *out) {
     extern __shared__ float4 sphere_win[];
-    __shared__ uint2 sobol_lds[16 * IRIS_SOBOL_SETS];
+    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     stage_tables(sobol_lds);
     DrawRing ring = ring_lds + threadIdx.x;
