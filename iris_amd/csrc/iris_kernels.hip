@@ -36,6 +36,17 @@ constexpr int BLOCK = 256;
 static_assert(BLOCK == IRIS_BLOCK, "the draw ring stride is the workgroup size");
 constexpr uint32_t STATE_ALIVE = 0x80000000u;
 
+// Exact n / d for n < 2^31 by one multiply-high (Granlund-Montgomery: m = ceil(2^(31+L) / d), L = ceil(log2 d)).
+struct FastDiv { uint32_t mul, shift; };  // shift = L - 1; divisor 1 is flagged by shift = 0xffffffff
+inline FastDiv make_fastdiv(uint32_t d) {
+    if (d <= 1u) return FastDiv{0u, 0xffffffffu};
+    uint32_t L = 0;
+    while ((1ull << L) < d) L++;
+    const unsigned long long m = ((1ull << (31 + L)) + d - 1) / d;
+    return FastDiv{(uint32_t)m, L - 1u};
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv fd) { return fd.shift == 0xffffffffu ? n : __umulhi(n, fd.mul) >> fd.shift; }
+
 struct Pool {
     float4 *rayo;  // (ox, oy, oz, hero wavelength)
     float4 *rayd;  // (dx, dy, dz, state bits: alive << 31 | bounce)
@@ -58,6 +69,7 @@ struct WfArgs {
     uint32_t *live_blocks;    // multi-kernel mode: workgroups that still have work after stage A
     unsigned long long *counters;  // samples, bounces, rays, sphere_tests
     uint32_t npix;
+    FastDiv div_npix, div_width;
     uint32_t s_begin;         // sample index of item 0 of this chunk
     uint32_t n_items;         // items in this chunk
     uint32_t items_per_block;
@@ -132,9 +144,9 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
         uint32_t item = 0u;
         if (regen) {
             item = (uint32_t)id;
-            uint32_t s_local = item / a.npix;
+            uint32_t s_local = fast_div(item, a.div_npix);
             uint32_t pix = item - s_local * a.npix;
-            uint32_t y = pix / a.fr.width;
+            uint32_t y = fast_div(pix, a.div_width);
             uint32_t x = pix - y * a.fr.width;
             raygen(a.cam, a.fr, tab, ring, x, y, a.s_begin + s_local, ps);
             cnt.samples++;
@@ -360,9 +372,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             uint32_t new_item = 0u, sample_index = 0u;
             if (valid) {
                 new_item = (uint32_t)id;
-                uint32_t s_local = new_item / a.npix;
+                uint32_t s_local = fast_div(new_item, a.div_npix);
                 uint32_t pix = new_item - s_local * a.npix;
-                uint32_t y = pix / a.fr.width;
+                uint32_t y = fast_div(pix, a.div_width);
                 uint32_t x = pix - y * a.fr.width;
                 sample_index = a.s_begin + s_local;
                 cs = camera_sample(a.cam, a.fr, sobol_lds, x, y, sample_index);
@@ -834,6 +846,8 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.live_blocks = c->d_live;
         a.counters = c->d_counters;
         a.npix = npix;
+        a.div_npix = make_fastdiv(npix);
+        a.div_width = make_fastdiv(p->width);
         a.s_begin = p->spp_begin + done;
         a.n_items = n_s * npix;
         a.items_per_block = ((a.n_items + blocks * 64u - 1) / (blocks * 64u)) * 64u;  // whole runs of 64
