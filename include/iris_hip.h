@@ -184,6 +184,19 @@ int iris_camera_new(const float position[3], float aspect_ratio, iris_camera *ou
  * (bsdf/microfacet.rs:21-29) at scene construction. */
 float iris_roughness_to_alpha(float roughness);
 
+/* UpsampleTable (spectrum/upsample.rs:5-9): the RGB -> sigmoid-polynomial coefficient table of
+ * data/srgb.coeff.  Host-side, used while a scene is built (the reference calls it from scene
+ * construction only).  load = UpsampleTable::load (upsample.rs:108-144; file format in its comment and in
+ * tools/rgb2spec_opt.c, which regenerates the file the reference tree lacks); get_spectrum =
+ * upsample.rs:59-106 (trilinear look-up, find_interval :147-165), result kind IRIS_SPEC_UPSAMPLED;
+ * get_spectrum_hdr = upsample.rs:46-56, result kind IRIS_SPEC_UPSAMPLED_HDR. */
+typedef struct iris_upsample_table iris_upsample_table;
+int iris_upsample_table_load(const char *path, iris_upsample_table **out);
+void iris_upsample_table_free(iris_upsample_table *table);
+uint32_t iris_upsample_table_resolution(const iris_upsample_table *table);
+int iris_upsample_get_spectrum(const iris_upsample_table *table, const float rgb[3], iris_spectrum *out);
+int iris_upsample_get_spectrum_hdr(const iris_upsample_table *table, const float rgb[3], iris_spectrum *out);
+
 /* ---- the hot path ----------------------------------------------------- */
 
 /* Renders sample indices [spp_begin, spp_begin+spp_count) of every pixel and

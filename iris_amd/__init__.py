@@ -12,5 +12,5 @@ from .ffi import IrisError  # noqa: F401
 from .render import Camera, HipWavefront, Render, film_to_rgb  # noqa: F401
 from .scene import (  # noqa: F401
     HWSS_NAIVE, HWSS_SLOW, SWSS_NAIVE, SWSS_SLOW, INTEGRATORS, ConstantSpectrum, FresnelBsdf, LambertianBsdf,
-    MicrofacetBsdf, NullBsdf, Scene, SpecularBsdf, Sphere, UpsampledHdrSpectrum, UpsampledSpectrum,
+    MicrofacetBsdf, NullBsdf, Scene, SpecularBsdf, Sphere, UpsampledHdrSpectrum, UpsampledSpectrum, UpsampleTable,
 )

@@ -2,7 +2,11 @@
 // once per render on the CPU (camera matrices, roughness mapping, XYZ -> RGB).  Plain C++, no HIP.
 // Compiled with -ffp-contract=off: one IEEE-754 operation per source operation, as in the reference.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <new>
+#include <algorithm>
+#include <vector>
 
 #include "../../include/iris_hip.h"
 
@@ -118,6 +122,123 @@ int iris_film_to_rgb(const float *xyz, size_t n_pixels, float *rgb) {
         rgb[3 * i + 1] = (g != g) ? 0.0f : (g < 0.0f ? 0.0f : g);
         rgb[3 * i + 2] = (b != b) ? 0.0f : (b < 0.0f ? 0.0f : b);
     }
+    return IRIS_OK;
+}
+
+// ---- UpsampleTable (spectrum/upsample.rs:5-9, :44-165): host-side, used while a scene is built ----
+}  // extern "C"
+
+struct iris_upsample_table {
+    std::vector<float> coefficients, scale;
+    size_t resolution = 0;
+};
+
+namespace {
+
+// Rust `f32 as usize`: saturating, NaN -> 0
+size_t f_as_usize(float f) {
+    if (!(f > 0.0f)) return 0;
+    if (f >= 18446744073709551616.0f) return ~(size_t)0;
+    return (size_t)f;
+}
+float rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
+float rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
+
+// find_interval, upsample.rs:147-165
+size_t find_interval(const std::vector<float> &values, size_t size_in, float x) {
+    size_t left = 0;
+    const size_t last_interval = size_in - 2;
+    size_t size = last_interval;
+    while (size > 0) {
+        const size_t half = size / 2, middle = left + half + 1;
+        if (values[middle] < x) {
+            left = middle;
+            size -= half + 1;
+        } else {
+            size = half;
+        }
+    }
+    return left < last_interval ? left : last_interval;
+}
+
+// UpsampleTable::get_spectrum, upsample.rs:59-106
+void get_spectrum(const iris_upsample_table &t, const float rgb[3], float out[3]) {
+    size_t i = 0;
+    const size_t res = t.resolution;
+    for (size_t j = 1; j < 3; j++)
+        if (rgb[j] >= rgb[i]) i = j;
+    const float z = rgb[i];
+    const float scale = (float)(res - 1) / z;
+    const float x = rgb[(i + 1) % 3] * scale;
+    const float y = rgb[(i + 2) % 3] * scale;
+    const size_t xi = std::min(f_as_usize(x), res - 2), yi = std::min(f_as_usize(y), res - 2);
+    const size_t zi = find_interval(t.scale, res, z);
+    size_t offset = (((i * res + zi) * res + yi) * res + xi) * 3;
+    const size_t dx = 3, dy = 3 * res, dz = 3 * res * res;
+    const float x1 = x - (float)xi, x0 = 1.0f - x1, y1 = y - (float)yi, y0 = 1.0f - y1;
+    const float z1 = (z - t.scale[zi]) / (t.scale[zi + 1] - t.scale[zi]), z0 = 1.0f - z1;
+    const float *c = t.coefficients.data();
+    for (int k = 0; k < 3; k++) {
+        out[k] = ((c[offset] * x0 + c[offset + dx] * x1) * y0 + (c[offset + dy] * x0 + c[offset + dy + dx] * x1) * y1) * z0 +
+                 ((c[offset + dz] * x0 + c[offset + dz + dx] * x1) * y0 + (c[offset + dz + dy] * x0 + c[offset + dz + dy + dx] * x1) * y1) * z1;
+        offset += 1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// UpsampleTable::load, upsample.rs:108-144.  The reference panics on a bad header and would index out of
+// bounds later on a short file; here both are IRIS_E_ARG at load time.
+int iris_upsample_table_load(const char *path, iris_upsample_table **out) {
+    if (!path || !out) return IRIS_E_ARG;
+    *out = nullptr;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return IRIS_E_ARG;
+    unsigned char head[8];
+    iris_upsample_table *t = new (std::nothrow) iris_upsample_table();
+    bool ok = t && std::fread(head, 1, 8, f) == 8 && std::memcmp(head, "SPEC", 4) == 0;
+    if (ok) {
+        const uint32_t res = (uint32_t)head[4] | ((uint32_t)head[5] << 8) | ((uint32_t)head[6] << 16) | ((uint32_t)head[7] << 24);
+        ok = res >= 2 && res <= 1024;
+        if (ok) {
+            t->resolution = res;
+            t->scale.resize(res);
+            t->coefficients.resize((size_t)9 * res * res * res);
+            ok = std::fread(t->scale.data(), sizeof(float), res, f) == res &&  // little-endian host
+                 std::fread(t->coefficients.data(), sizeof(float), t->coefficients.size(), f) == t->coefficients.size();
+        }
+    }
+    std::fclose(f);
+    if (!ok) {
+        delete t;
+        return IRIS_E_ARG;
+    }
+    *out = t;
+    return IRIS_OK;
+}
+
+void iris_upsample_table_free(iris_upsample_table *t) { delete t; }
+
+uint32_t iris_upsample_table_resolution(const iris_upsample_table *t) { return t ? (uint32_t)t->resolution : 0u; }
+
+int iris_upsample_get_spectrum(const iris_upsample_table *t, const float rgb[3], iris_spectrum *out) {
+    if (!t || !rgb || !out) return IRIS_E_ARG;
+    float c[3];
+    get_spectrum(*t, rgb, c);
+    *out = iris_spectrum{IRIS_SPEC_UPSAMPLED, c[0], c[1], c[2], 0.0f};
+    return IRIS_OK;
+}
+
+// UpsampleTable::get_spectrum_hdr, upsample.rs:46-56 (including its clamp of the HDR factor at 50)
+int iris_upsample_get_spectrum_hdr(const iris_upsample_table *t, const float rgb[3], iris_spectrum *out) {
+    if (!t || !rgb || !out) return IRIS_E_ARG;
+    const float max = rust_max(rust_max(rust_max(rgb[0], rgb[1]), rgb[2]), 1.0f);
+    const float n[3] = {rgb[0] / max, rgb[1] / max, rgb[2] / max};
+    float c[3];
+    get_spectrum(*t, n, c);
+    *out = iris_spectrum{IRIS_SPEC_UPSAMPLED_HDR, c[0], c[1], c[2], rust_min(max, 50.0f)};
     return IRIS_OK;
 }
 

@@ -18,7 +18,8 @@ TRACE_MAX_DEPTH = 64
 EXPORTS = (
     "iris_ctx_create", "iris_ctx_destroy", "iris_last_error", "iris_ctx_set_option", "iris_scene_upload",
     "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_film_to_rgb",
-    "iris_get_stats", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
+    "iris_get_stats", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
+    "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
 )
 
 
@@ -100,6 +101,11 @@ def load():
         "iris_render_device": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp]),
         "iris_film_to_rgb": (C.c_int, [fp, C.c_size_t, fp]),
         "iris_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "iris_upsample_table_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "iris_upsample_table_free": (None, [vp]),
+        "iris_upsample_table_resolution": (C.c_uint32, [vp]),
+        "iris_upsample_get_spectrum": (C.c_int, [vp, fp, C.POINTER(Spectrum)]),
+        "iris_upsample_get_spectrum_hdr": (C.c_int, [vp, fp, C.POINTER(Spectrum)]),
         "iris_dbg_sampler": (C.c_int, [vp, u32, u32p, u32, u32, fp]),
         "iris_dbg_raygen": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(RenderParams), u32, u32p, fp, fp, fp]),
         "iris_dbg_intersect": (C.c_int, [vp, u32, fp, fp, i32p, fp]),

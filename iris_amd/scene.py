@@ -56,6 +56,48 @@ class UpsampledHdrSpectrum:  # spectrum/upsample.rs:27-42
         return (SPEC_UPSAMPLED_HDR, _f32(c[0]), _f32(c[1]), _f32(c[2]), _f32(self.hdr_coefficient))
 
 
+class UpsampleTable:
+    """spectrum/upsample.rs:5-9, :44-165: the RGB -> sigmoid-polynomial table of data/srgb.coeff.  The file is
+    not in the reference tree; tools/rgb2spec_opt.c regenerates one in the same format."""
+
+    def __init__(self, path):  # UpsampleTable::load, upsample.rs:108-144
+        self.L = ffi.load()
+        self.handle = C.c_void_p()
+        rc = self.L.iris_upsample_table_load(str(path).encode(), C.byref(self.handle))
+        if rc != ffi.IRIS_OK:
+            self.handle = None
+            raise ffi.IrisError("iris_upsample_table_load(%s) failed (%d): missing file, bad header or short file" % (path, rc))
+
+    load = classmethod(lambda cls, path: cls(path))
+
+    @property
+    def resolution(self):
+        return int(self.L.iris_upsample_table_resolution(self.handle))
+
+    def _call(self, fn, rgb):
+        arr = (C.c_float * 3)(*[float(np.float32(v)) for v in rgb])
+        out = ffi.Spectrum()
+        rc = fn(self.handle, arr, C.byref(out))
+        if rc != ffi.IRIS_OK:
+            raise ffi.IrisError("upsample look-up failed (%d)" % rc)
+        return out
+
+    def get_spectrum(self, rgb):  # upsample.rs:59-106
+        o = self._call(self.L.iris_upsample_get_spectrum, rgb)
+        return UpsampledSpectrum((o.c0, o.c1, o.c2))
+
+    def get_spectrum_hdr(self, rgb):  # upsample.rs:46-56
+        o = self._call(self.L.iris_upsample_get_spectrum_hdr, rgb)
+        return UpsampledHdrSpectrum((o.c0, o.c1, o.c2), o.hdr)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.iris_upsample_table_free(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
 # ---- shape/ ----------------------------------------------------------------
 @dataclass
 class Sphere:  # shape/sphere.rs:7-16
@@ -204,6 +246,19 @@ class Scene:
         scene.add_material(Sphere((0.0, -101.5, 2.0), 100.0), LambertianBsdf(ConstantSpectrum(0.8)))
         scene.add_material(Sphere((-2.2, -0.2, 3.5), 1.0), MicrofacetBsdf(ConstantSpectrum(0.9), 0.2, 0.2))
         scene.add_material(Sphere((2.2, -0.2, 3.5), 1.0), SpecularBsdf(ConstantSpectrum(0.9)))
+        return scene
+
+    @classmethod
+    def coloured(cls, table):
+        """S1's geometry with RGB materials and an HDR RGB light, all through the upsampling table
+        (UpsampleTable::get_spectrum / get_spectrum_hdr, upsample.rs:46-106): exercises the sigmoid spectra."""
+        scene = cls()
+        scene.add_emissive_material(Sphere((0.0, 2.3, 3.0), 1.0), LambertianBsdf(table.get_spectrum((0.5, 0.5, 0.5))),
+                                    table.get_spectrum_hdr((4.0, 3.5, 3.0)))
+        scene.add_material(Sphere((0.0, -0.2, 3.0), 1.0), LambertianBsdf(table.get_spectrum((0.8, 0.15, 0.1))))
+        scene.add_material(Sphere((0.0, -101.5, 2.0), 100.0), LambertianBsdf(table.get_spectrum((0.2, 0.6, 0.3))))
+        scene.add_material(Sphere((-2.2, -0.2, 3.5), 1.0), MicrofacetBsdf(table.get_spectrum((0.9, 0.8, 0.3)), 0.3, 0.3))
+        scene.add_material(Sphere((2.2, -0.2, 3.5), 1.0), SpecularBsdf(table.get_spectrum((0.3, 0.5, 0.9))))
         return scene
 
     def flatten(self) -> FlatScene:

@@ -15,6 +15,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -582,6 +583,77 @@ static float spectrum_evaluate_single(const spectrum_t *s, float lambda) {
 static f4 spectrum_evaluate(const spectrum_t *s, f4 wl) {
     return f4_new(spectrum_evaluate_single(s, wl.v[0]), spectrum_evaluate_single(s, wl.v[1]),
                   spectrum_evaluate_single(s, wl.v[2]), spectrum_evaluate_single(s, wl.v[3]));
+}
+
+/* ---- UpsampleTable, upsample.rs:5-9 and :44-165 (host side: used while a scene is built) ---- */
+struct orc_upsample_table { float *coefficients; size_t n_coefficients; float *scale; size_t resolution; };
+
+/* UpsampleTable::load, upsample.rs:108-144: "SPEC", u32 LE resolution, resolution f32 LE, then f32 LE to the end */
+orc_upsample_table *orc_upsample_table_load(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    unsigned char sig[4], resb[4];
+    if (fread(sig, 1, 4, f) != 4 || memcmp(sig, "SPEC", 4) != 0 || fread(resb, 1, 4, f) != 4) { fclose(f); return NULL; }
+    orc_upsample_table *t = calloc(1, sizeof *t);
+    t->resolution = (size_t)resb[0] | ((size_t)resb[1] << 8) | ((size_t)resb[2] << 16) | ((size_t)resb[3] << 24);
+    t->scale = malloc(sizeof(float) * t->resolution);
+    if (fread(t->scale, sizeof(float), t->resolution, f) != t->resolution) { fclose(f); free(t->scale); free(t); return NULL; }
+    long at = ftell(f);
+    fseek(f, 0, SEEK_END);
+    long end = ftell(f);
+    fseek(f, at, SEEK_SET);
+    t->n_coefficients = (size_t)(end - at) / 4;
+    t->coefficients = malloc(sizeof(float) * (t->n_coefficients ? t->n_coefficients : 1));
+    if (fread(t->coefficients, sizeof(float), t->n_coefficients, f) != t->n_coefficients) { fclose(f); free(t->coefficients); free(t->scale); free(t); return NULL; }
+    fclose(f);
+    return t;
+}
+void orc_upsample_table_free(orc_upsample_table *t) {
+    if (t) { free(t->coefficients); free(t->scale); free(t); }
+}
+/* upsample.rs:147-165 */
+static size_t upsample_find_interval(const float *values, size_t size_in, float x) {
+    size_t left = 0, last_interval = size_in - 2, size = last_interval;
+    while (size > 0) {
+        size_t half = size / 2, middle = left + half + 1;
+        if (values[middle] < x) { left = middle; size -= half + 1; }
+        else size = half;
+    }
+    return left < last_interval ? left : last_interval;
+}
+/* UpsampleTable::get_spectrum, upsample.rs:59-106.  Returns 0 where the reference would panic (index out of bounds). */
+int orc_upsample_get_spectrum(const orc_upsample_table *t, const float rgb[3], float coefficients[3]) {
+    size_t i = 0, res = t->resolution;
+    for (size_t j = 1; j < 3; j++)
+        if (rgb[j] >= rgb[i]) i = j;
+    float z = rgb[i];
+    float scale = (float)(res - 1) / z;
+    float x = rgb[(i + 1) % 3] * scale;
+    float y = rgb[(i + 2) % 3] * scale;
+    size_t xi = f_as_usize(x), yi = f_as_usize(y);
+    if (xi > res - 2) xi = res - 2;
+    if (yi > res - 2) yi = res - 2;
+    size_t zi = upsample_find_interval(t->scale, res, z);
+    size_t offset = (((i * res + zi) * res + yi) * res + xi) * 3;
+    size_t dx = 3, dy = 3 * res, dz = 3 * res * res;
+    if (offset + dz + dy + dx + 2 >= t->n_coefficients) return 0;
+    float x1 = x - (float)xi, x0 = 1.0f - x1;
+    float y1 = y - (float)yi, y0 = 1.0f - y1;
+    float z1 = (z - t->scale[zi]) / (t->scale[zi + 1] - t->scale[zi]), z0 = 1.0f - z1;
+    const float *c = t->coefficients;
+    for (int k = 0; k < 3; k++) {
+        coefficients[k] = ((c[offset] * x0 + c[offset + dx] * x1) * y0 + (c[offset + dy] * x0 + c[offset + dy + dx] * x1) * y1) * z0
+                        + ((c[offset + dz] * x0 + c[offset + dz + dx] * x1) * y0 + (c[offset + dz + dy] * x0 + c[offset + dz + dy + dx] * x1) * y1) * z1;
+        offset += 1;
+    }
+    return 1;
+}
+/* UpsampleTable::get_spectrum_hdr, upsample.rs:46-56 */
+int orc_upsample_get_spectrum_hdr(const orc_upsample_table *t, const float rgb[3], float coefficients[3], float *hdr_coefficient) {
+    float max = rmax(rmax(rmax(rgb[0], rgb[1]), rgb[2]), 1.0f);
+    float n[3] = {rgb[0] / max, rgb[1] / max, rgb[2] / max};
+    *hdr_coefficient = rmin(max, 50.0f);
+    return orc_upsample_get_spectrum(t, n, coefficients);
 }
 
 const float *orc_cie_table(int which) { return which == 0 ? IRIS_CIE_X : (which == 1 ? IRIS_CIE_Y : IRIS_CIE_Z); }

@@ -111,6 +111,12 @@ float orc_vec4_dot(const float a[4], const float b[4]);
 float orc_vec4_sum(const float a[4]);
 float orc_fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t);
 float orc_roughness_to_alpha(float r);
+/* UpsampleTable, spectrum/upsample.rs:44-165 */
+typedef struct orc_upsample_table orc_upsample_table;
+orc_upsample_table *orc_upsample_table_load(const char *path);
+void orc_upsample_table_free(orc_upsample_table *t);
+int orc_upsample_get_spectrum(const orc_upsample_table *t, const float rgb[3], float coefficients[3]);
+int orc_upsample_get_spectrum_hdr(const orc_upsample_table *t, const float rgb[3], float coefficients[3], float *hdr_coefficient);
 
 /* camera.rs */
 void orc_camera_new(const float pos[3], float aspect_ratio, orc_camera *out);

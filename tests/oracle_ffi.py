@@ -82,6 +82,10 @@ def lib():
         "orc_roughness_to_alpha": (C.c_float, [C.c_float]),
         "orc_camera_new": (None, [fp, C.c_float, C.POINTER(Camera)]),
         "orc_upsampled_evaluate_single": (C.c_float, [fp, C.c_float]),
+        "orc_upsample_table_load": (C.c_void_p, [C.c_char_p]),
+        "orc_upsample_table_free": (None, [C.c_void_p]),
+        "orc_upsample_get_spectrum": (C.c_int, [C.c_void_p, fp, fp]),
+        "orc_upsample_get_spectrum_hdr": (C.c_int, [C.c_void_p, fp, fp, fp]),
         "orc_xyz_from_wavelength": (None, [C.c_float, C.c_float, fp]),
         "orc_xyz_to_rgb_hdr": (None, [fp, fp]),
         "orc_cie_table": (fp, [C.c_int]),

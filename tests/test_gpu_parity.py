@@ -43,7 +43,9 @@ def random_xys(rng, w, h, spp, n):
 
 
 def make(scene_name):
-    from iris_amd import Scene
+    from iris_amd import Scene, UpsampleTable
+    if scene_name == "coloured":  # sigmoid-polynomial spectra from the upsampling table (rows a25, a26)
+        return Scene.coloured(UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff")))
     return {"s1": Scene.dummy, "s3": Scene.glossy_dielectric, "furnace": Scene.furnace,
             "s2_small": lambda: Scene.many_spheres(600), "s2_chunked": lambda: Scene.many_spheres(2500)}[scene_name]()
 
@@ -127,7 +129,7 @@ def test_intersect_tie_breaks_to_lowest_index(gpu, iris_trig):
 
 @pytest.mark.parametrize("scene_name,integrator,max_depth", [
     ("s1", 0, 15), ("s1", 1, 15), ("s1", 2, 15), ("s1", 3, 15), ("s3", 0, 32), ("s3", 2, 32), ("s3", 1, 32),
-    ("furnace", 0, 15), ("s2_small", 0, 15)])
+    ("furnace", 0, 15), ("s2_small", 0, 15), ("coloured", 0, 15), ("coloured", 3, 15)])
 def test_path_trace_bit_exact(gpu, iris_trig, scene_name, integrator, max_depth):
     """Whole camera samples: hit indices and t per bounce, sampler draw count, 4-wavelength radiance and
     XYZ, for every integrator (integrator/*.rs) and every BSDF (bsdf/*.rs; s3 has all of them)."""
@@ -174,7 +176,7 @@ def oracle_film(O, flat, w, h, spp, **kw):
 @pytest.mark.parametrize("scene_name,w,h,spp,integrator,max_depth", [
     ("s1", 64, 64, 8, 0, 15), ("s1", 70, 33, 5, 0, 15), ("s1", 1, 1, 3, 0, 15), ("s1", 48, 48, 6, 1, 15),
     ("s1", 48, 48, 6, 2, 15), ("s1", 48, 48, 6, 3, 15), ("s3", 64, 48, 16, 0, 32), ("furnace", 16, 16, 32, 0, 15),
-    ("s2_small", 48, 32, 4, 0, 15), ("s1", 40, 40, 4, 0, 1), ("s1", 40, 40, 4, 0, 0)])
+    ("s2_small", 48, 32, 4, 0, 15), ("s1", 40, 40, 4, 0, 1), ("s1", 40, 40, 4, 0, 0), ("coloured", 64, 48, 16, 0, 15)])
 def test_film_bit_exact(gpu, iris_trig, scene_name, w, h, spp, integrator, max_depth):
     """The film get_pixel_color produces (tile.rs:127-166), samples summed in index order, and the exact
     work counters, for ragged sizes, every integrator and a depth-0 / depth-1 loop."""
