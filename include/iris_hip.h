@@ -166,6 +166,9 @@ const char *iris_last_error(const iris_ctx *ctx);
  *                     rays compacted before every scan); 2: register-resident kernel (needs the
  *                     sphere list to fit the LDS window)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 32)
+ *   "bvh_min_prims"   scenes with at least this many spheres get a bounding-volume hierarchy at upload and the
+ *                     scans traverse it (default 65; 0 = never: every scan tests every sphere like scene.rs:116-166).
+ *                     Closest hit and tie rule are the list scan's; iris_stats.sphere_tests then counts the tests made
  *   "specialize"      1 (default): scenes with only Lambertian BSDFs over constant spectra (the reference's
  *                     default scene) run kernels compiled for that class; 0: always the general kernels
  * None of them changes a single bit of the result.

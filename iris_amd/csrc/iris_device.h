@@ -424,6 +424,13 @@ struct SceneDev {
     const iris_spectrum *spectra;
     const iris_light *lights;
     uint32_t n_prims, n_lights;
+    // Bounding-volume hierarchy over the spheres (long lists only; n_bvh_nodes == 0: none).  Node k is two
+    // float4: (lo.xyz, first) and (hi.xyz, count); count > 0: leaf holding leaf-ordered spheres
+    // [first, first + count); count == 0: inner node whose children are nodes first and first + 1.
+    const float4 *bvh_nodes;
+    const float4 *bvh_spheres;   // (cx, cy, cz, r * r) in leaf order
+    const uint32_t *bvh_prim;    // primitive index of each leaf-ordered sphere
+    uint32_t n_bvh_nodes;
 };
 
 // shape/mod.rs:14-38
@@ -488,7 +495,10 @@ struct SphereStage {
     float4 *lds;           // window
     uint32_t cap;          // window capacity in spheres (a multiple of IRIS_SCAN_PAD)
     bool resident;         // n_prims <= cap and the window already holds the list
+    bool bvh;              // the scene has a hierarchy: the scans traverse it instead of the list
+    uint32_t *stack;       // bvh: this lane's traversal stack in LDS, entry k at stack[k * IRIS_BLOCK]
 };
+#define IRIS_BVH_STACK 24u   // entries per lane; the host builds no hierarchy deeper than this
 
 // One pass over `n` staged spheres (n real ones, followed by fillers up to a multiple of IRIS_SCAN_PAD),
 // B at a time: the B LDS reads of a batch are issued together, so their latency is paid once per batch.
@@ -505,17 +515,86 @@ IRIS_DEV void scan_window(const float4 *win, uint32_t n, uint32_t base, const Ra
     }
 }
 
+// ---- the same closest-hit query through the hierarchy ----
+// The answer must be the linear scan's, bit for bit: the closest t > 0 with the lowest primitive index on
+// ties (scene.rs:116-132).  Every sphere is tested with the very same sphere arithmetic; the hierarchy only
+// decides which spheres are tested.  A subtree is skipped only if the ray misses its (host-inflated) box or
+// enters it strictly behind the closest hit so far, so a sphere that could win or tie is always visited;
+// visiting order is free, hence the explicit tie rule on the index.
+IRIS_DEV float box_entry(float4 lo, float4 hi, V3 o, V3 inv, float closest_t) {
+    float tx0 = (lo.x - o.x) * inv.x, tx1 = (hi.x - o.x) * inv.x;
+    float ty0 = (lo.y - o.y) * inv.y, ty1 = (hi.y - o.y) * inv.y;
+    float tz0 = (lo.z - o.z) * inv.z, tz1 = (hi.z - o.z) * inv.z;
+    // fminf / fmaxf ignore a NaN operand (0 * inf when the origin lies on a slab plane of an axis-parallel ray)
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fmaxf(__builtin_fminf(tz0, tz1), 0.0f));
+    float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));
+    return (tmin <= tmax && tmin <= closest_t) ? tmin : __builtin_inff();  // inf: do not enter
+}
+IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests) {
+    const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    uint32_t sp = 0u, node = 0u;
+    uint32_t n_tests = 0u;
+    if (!(box_entry(sc.bvh_nodes[0], sc.bvh_nodes[1], ray.o, inv, closest_t) < __builtin_inff())) return;
+    for (;;) {
+        const float4 n0 = sc.bvh_nodes[2u * node], n1 = sc.bvh_nodes[2u * node + 1u];
+        const uint32_t first = __float_as_uint(n0.w), count = __float_as_uint(n1.w);
+        bool pop = true;
+        if (count != 0u) {
+            for (uint32_t k = 0; k < count; k++) {
+                const float4 sp4 = sc.bvh_spheres[first + k];
+                const int index = (int)sc.bvh_prim[first + k];
+                V3 oc = ray.o - v3(sp4.x, sp4.y, sp4.z);
+                float half_b = dot(ray.d, oc);
+                float c = len_squared(oc) - sp4.w;
+                float discrim = half_b * half_b - a * c;
+                if (discrim > 0.0f) {  // sphere.rs:31-35, :53
+                    float root = rsqrt_exact(discrim);
+                    float temp = (-half_b - root) / a;
+                    if (!(temp > 0.0f)) temp = (-half_b + root) / a;
+                    if (temp > 0.0f && (temp < closest_t || (temp == closest_t && index < closest))) { closest_t = temp; closest = index; }
+                }
+            }
+            n_tests += count;
+        } else {
+            const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
+            const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];
+            const float tl = box_entry(l0, l1, ray.o, inv, closest_t), tr = box_entry(r0, r1, ray.o, inv, closest_t);
+            const bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
+            if (hl || hr) {
+                pop = false;
+                const bool left_first = hl && (!hr || tl <= tr);
+                node = left_first ? first : first + 1u;
+                if (hl && hr) {  // the farther child waits on the stack (depth <= IRIS_BVH_STACK by construction)
+                    stack[sp * IRIS_BLOCK] = left_first ? first + 1u : first;
+                    sp++;
+                }
+            }
+        }
+        if (pop) {
+            if (sp == 0u) break;
+            sp--;
+            node = stack[sp * IRIS_BLOCK];
+        }
+    }
+    tests += n_tests;
+}
+
 // Scene::intersection / ray_hits_point / ray_hits_object all reduce to this scan (scene.rs:116-166):
 // closest t > 0 over all primitives in index order, strict '<' so the lowest index wins ties.
 // Must be called by every thread of the workgroup (inactive threads pass active=false) because a
 // list larger than the LDS window is staged cooperatively.
-IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool active, const Ray &ray, float &t_out, int &prim_out) {
+// `tests` counts the Sphere::intersect evaluations made for active lanes (list scans: n_prims each).
+IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool active, const Ray &ray, float &t_out, int &prim_out, unsigned long long &tests) {
     float closest_t = __builtin_inff();
     int closest = -1;
     float a = len_squared(ray.d);  // sphere.rs:27 (loop-invariant)
-    if (st.resident) {
+    if (st.bvh) {
+        if (active) bvh_closest(sc, st.stack, ray, a, closest_t, closest, tests);
+    } else if (st.resident) {
         if (active) scan_window<4>(st.lds, sc.n_prims, 0u, ray, a, closest_t, closest);
+        if (active) tests += sc.n_prims;
     } else {
+        if (active) tests += sc.n_prims;
         for (uint32_t base = 0; base < sc.n_prims; base += st.cap) {
             uint32_t n = sc.n_prims - base < st.cap ? sc.n_prims - base : st.cap;
             uint32_t n_pad = (n + IRIS_SCAN_PAD - 1u) & ~(IRIS_SCAN_PAD - 1u);
@@ -862,10 +941,9 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         }
         float st1;
         int sp1;
-        scan_closest(sc, st, want1, shadow1, st1, sp1);  // scene.rs:134-149
+        scan_closest(sc, st, want1, shadow1, st1, sp1, cnt.sphere_tests);  // scene.rs:134-149
         if (want1) {
             cnt.rays++;
-            cnt.sphere_tests += sc.n_prims;
             float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
             if (st1 > target_t - IRIS_RAY_EPSILON) {
                 V3 shading_wi = world_to_shading(hit, shadow1.d);
@@ -890,10 +968,9 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         }
         float st2;
         int sp2;
-        scan_closest(sc, st, want2, shadow2, st2, sp2);  // scene.rs:151-166
+        scan_closest(sc, st, want2, shadow2, st2, sp2, cnt.sphere_tests);  // scene.rs:151-166
         if (want2) {
             cnt.rays++;
-            cnt.sphere_tests += sc.n_prims;
             if (sp2 == light_prim) {
                 float lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
                 float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : hero(bs_pdfs) / (hero(bs_pdfs) + lpdf);

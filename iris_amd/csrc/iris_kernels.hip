@@ -103,7 +103,9 @@ __device__ __forceinline__ SphereStage stage_spheres(const SceneDev &sc, float4 
     SphereStage st;
     st.lds = win;
     st.cap = cap;
-    st.resident = sc.n_prims <= cap;
+    st.bvh = sc.n_bvh_nodes != 0u;
+    st.stack = (uint32_t *)win + threadIdx.x;  // hierarchy: the window's LDS holds the traversal stacks instead
+    st.resident = !st.bvh && sc.n_prims <= cap;
     if (st.resident) {
         const uint32_t n_pad = (sc.n_prims + IRIS_SCAN_PAD - 1u) & ~(IRIS_SCAN_PAD - 1u);
         for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) win[i] = i < sc.n_prims ? stage_sphere(sc.spheres[i]) : stage_filler();
@@ -162,8 +164,8 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
         const bool active = regen || was_alive;
         float t;
         int prim;
-        scan_closest(a.sc, st, active, ps.ray, t, prim);
-        if (active) { cnt.rays++; cnt.sphere_tests += a.sc.n_prims; }
+        scan_closest(a.sc, st, active, ps.ray, t, prim, cnt.sphere_tests);
+        if (active) cnt.rays++;
         const bool hitp = active && prim >= 0;
         if (active && !hitp) {  // the path left the scene: `None => break` (hwss_naive.rs:41-44)
             if (regen) {
@@ -346,10 +348,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             if (__ballot(active) != 0ull) {
                 float t_new;
                 int prim_new;
-                scan_closest(a.sc, st, active, ps.ray, t_new, prim_new);
+                scan_closest(a.sc, st, active, ps.ray, t_new, prim_new, cnt.sphere_tests);
                 if (active) {
                     cnt.rays++;
-                    cnt.sphere_tests += a.sc.n_prims;
                     t = t_new;
                     prim = prim_new;
                     if (prim >= 0) {
@@ -383,10 +384,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             }
             float t_new;
             int prim_new;
-            scan_closest(a.sc, st, valid, ray, t_new, prim_new);
+            scan_closest(a.sc, st, valid, ray, t_new, prim_new, cnt.sphere_tests);
             if (valid) {
                 cnt.rays++;
-                cnt.sphere_tests += a.sc.n_prims;
                 if (prim_new < 0) store_result(a, new_item, v3(0.0f, 0.0f, 0.0f));  // radiance is exactly zero: `None => break`
             }
             const bool hitp = valid && prim_new >= 0;
@@ -550,7 +550,8 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_intersect(SceneDev sc, uint32_t c
     if (active) { ray.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); ray.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]); }
     float t;
     int prim;
-    scan_closest(sc, st, active, ray, t, prim);
+    unsigned long long tests = 0ull;
+    scan_closest(sc, st, active, ray, t, prim, tests);
     if (active) { prim_out[i] = prim; t_out[i] = t; }
 }
 template <int INTEG>
@@ -583,7 +584,7 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, Fr
     while (__syncthreads_or(alive ? 1 : 0)) {
         float t;
         int prim;
-        scan_closest(sc, st, alive, ps.ray, t, prim);
+        scan_closest(sc, st, alive, ps.ray, t, prim, cnt.sphere_tests);
         if (alive && prim < 0) alive = false;
         if (alive) {
             if (n_hits < IRIS_TRACE_MAX_DEPTH) { tr->hit_prim[n_hits] = prim; tr->hit_t[n_hits] = t; }
@@ -618,6 +619,7 @@ struct iris_ctx {
     int64_t multi_kernel = 0;
     int64_t mode = 0;             // 0 auto, 1 pool/queue kernels, 2 register-resident kernel
     int64_t reg_blocks_per_cu = 32;  // register-resident kernel: more workgroups than fit, for a short tail
+    int64_t bvh_min_prims = 65;   // build a hierarchy for scenes with at least this many spheres (0: never)
     int64_t specialize = 1;       // 1: use the kernel compiled for the scene's class; 0: always the general kernel
     int scene_class = IRIS_CLS_GENERAL;
     // scene
@@ -625,6 +627,8 @@ struct iris_ctx {
     bool scene_is_lambert_constant = false;
     SceneDev sc = {};
     void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr;
+    void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr;
+    uint32_t bvh_depth = 0;
     // pools
     uint32_t pool_blocks = 0, pool_slots_per_block = 0;
     Pool pool = {};
@@ -642,6 +646,74 @@ struct iris_ctx {
 namespace {
 
 constexpr uint32_t SPHERE_CAP = 1024;  // LDS window: 16 KiB of float4 (three pool-kernel workgroups per CU stay resident)
+
+// ---- host-side hierarchy build: balanced median splits of the sphere centres along the widest axis ----
+struct Bvh {
+    std::vector<float4> nodes;    // two per node: (lo, first), (hi, count)
+    std::vector<float4> spheres;  // (cx, cy, cz, r * r) in leaf order
+    std::vector<uint32_t> prim;
+    uint32_t depth = 0;
+};
+constexpr uint32_t BVH_LEAF = 4;
+float4 with_bits(float x, float y, float z, uint32_t w) {
+    float f;
+    std::memcpy(&f, &w, 4);
+    return make_float4(x, y, z, f);
+}
+void build_bvh_node(const iris_sphere *sp, std::vector<uint32_t> &order, uint32_t begin, uint32_t end, uint32_t node, uint32_t depth, Bvh &out) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = begin; i < end; i++) {
+        const iris_sphere &s = sp[order[i]];
+        const float c[3] = {s.cx, s.cy, s.cz}, r = std::fabs(s.r);
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], c[k] - r); hi[k] = std::max(hi[k], c[k] + r);
+            clo[k] = std::min(clo[k], c[k]); chi[k] = std::max(chi[k], c[k]);
+        }
+    }
+    // Inflate: a hit point computed in f32 lies within a few ulps of the sphere, i.e. of the exact box; the pad is
+    // some thousand ulps of the largest coordinate, so no sphere that the list scan would report is ever culled.
+    float mag = 1.0f;
+    for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+    const float pad = 1e-3f * mag;
+    for (int k = 0; k < 3; k++) { lo[k] -= pad; hi[k] += pad; }
+    out.depth = std::max(out.depth, depth);
+    if (end - begin <= BVH_LEAF) {
+        // leaf: spheres in ascending primitive order
+        std::sort(order.begin() + begin, order.begin() + end);
+        out.nodes[2 * node] = with_bits(lo[0], lo[1], lo[2], begin);
+        out.nodes[2 * node + 1] = with_bits(hi[0], hi[1], hi[2], end - begin);
+        return;
+    }
+    int axis = 0;
+    for (int k = 1; k < 3; k++)
+        if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    const uint32_t mid = begin + (end - begin) / 2;
+    std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](uint32_t a, uint32_t b) {
+        const float ca = axis == 0 ? sp[a].cx : (axis == 1 ? sp[a].cy : sp[a].cz), cb = axis == 0 ? sp[b].cx : (axis == 1 ? sp[b].cy : sp[b].cz);
+        return ca < cb || (ca == cb && a < b);
+    });
+    const uint32_t left = (uint32_t)(out.nodes.size() / 2);
+    out.nodes.resize(out.nodes.size() + 4);
+    out.nodes[2 * node] = with_bits(lo[0], lo[1], lo[2], left);
+    out.nodes[2 * node + 1] = with_bits(hi[0], hi[1], hi[2], 0u);
+    build_bvh_node(sp, order, begin, mid, left, depth + 1, out);
+    build_bvh_node(sp, order, mid, end, left + 1, depth + 1, out);
+}
+// false: no hierarchy (non-finite geometry, or deeper than the traversal stack) -- the list scan is used instead
+bool build_bvh(const iris_sphere *sp, uint32_t n, Bvh &out) {
+    for (uint32_t i = 0; i < n; i++)
+        if (!std::isfinite(sp[i].cx) || !std::isfinite(sp[i].cy) || !std::isfinite(sp[i].cz) || !std::isfinite(sp[i].r)) return false;
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    out.nodes.assign(2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    build_bvh_node(sp, order, 0, n, 0, 1, out);
+    if (out.depth > IRIS_BVH_STACK) return false;
+    out.spheres.resize(n);
+    out.prim = order;
+    for (uint32_t i = 0; i < n; i++) out.spheres[i] = make_float4(sp[order[i]].cx, sp[order[i]].cy, sp[order[i]].cz, sp[order[i]].r * sp[order[i]].r);
+    return true;
+}
 
 int fail(iris_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
@@ -719,8 +791,10 @@ FrameDev frame_dev(const iris_render_params *p) {
     FrameDev f = {p->width, p->height, p->seed, p->max_depth, p->min_depth};
     return f;
 }
-// window capacity in spheres: the list rounded up to whole scan batches, at most SPHERE_CAP
+// window capacity in spheres: the list rounded up to whole scan batches, at most SPHERE_CAP; with a hierarchy
+// the same LDS holds the traversal stacks (IRIS_BVH_STACK dwords per lane)
 uint32_t sphere_cap_for(const iris_ctx *c) {
+    if (c->sc.n_bvh_nodes) return IRIS_BVH_STACK * BLOCK * sizeof(uint32_t) / sizeof(float4);
     return std::min<uint32_t>((std::max<uint32_t>(c->sc.n_prims, 1u) + IRIS_SCAN_PAD - 1u) & ~(IRIS_SCAN_PAD - 1u), SPHERE_CAP);
 }
 static_assert(SPHERE_CAP % IRIS_SCAN_PAD == 0, "the LDS window holds whole scan batches");
@@ -731,6 +805,7 @@ static_assert(SPHERE_CAP % IRIS_SCAN_PAD == 0, "the LDS window holds whole scan 
 constexpr uint32_t REGISTER_KERNEL_MAX_PRIMS = 64;
 bool use_register_kernel(const iris_ctx *c) {
     if (c->multi_kernel || c->mode == 1) return false;
+    if (c->sc.n_bvh_nodes) return c->mode == 2;
     if (c->sc.n_prims > SPHERE_CAP) return false;
     return c->mode == 2 || c->sc.n_prims <= REGISTER_KERNEL_MAX_PRIMS;
 }
@@ -919,6 +994,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     (void)hipSetDevice(c->device);
     free_pools(c);
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
+    dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -946,6 +1022,9 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "mode") {
         if (value < 0 || value > 2) return fail(c, IRIS_E_ARG, "mode must be 0 (auto), 1 (pool) or 2 (register)");
         c->mode = value;
+    } else if (k == "bvh_min_prims") {
+        if (value < 0) return fail(c, IRIS_E_ARG, "bvh_min_prims must be >= 0");
+        c->bvh_min_prims = value;  // takes effect at the next iris_scene_upload
     } else if (k == "specialize") {
         c->specialize = value ? 1 : 0;
         c->scene_class = (c->specialize && c->scene_is_lambert_constant) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL;
@@ -983,7 +1062,10 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     }
     HIP_TRY(c, hipSetDevice(c->device));
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
+    dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     c->d_spheres = c->d_prim_info = c->d_bsdfs = c->d_spectra = c->d_lights = nullptr;
+    c->d_bvh_nodes = c->d_bvh_spheres = c->d_bvh_prim = nullptr;
+    c->sc = SceneDev{};
     c->have_scene = false;
     std::vector<int2> info(s->n_prims);
     for (uint32_t i = 0; i < s->n_prims; i++) info[i] = make_int2(s->prim_material[i], s->prim_light[i]);
@@ -1004,6 +1086,21 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     c->sc.lights = (const iris_light *)c->d_lights;
     c->sc.n_prims = s->n_prims;
     c->sc.n_lights = s->n_lights;
+    // hierarchy for long lists (the scans then visit O(log n) spheres; the answer is the linear scan's bit for bit)
+    c->bvh_depth = 0;
+    if (c->bvh_min_prims > 0 && (int64_t)s->n_prims >= c->bvh_min_prims) {
+        Bvh bvh;
+        if (build_bvh(s->spheres, s->n_prims, bvh)) {
+            HIP_TRY(c, up(&c->d_bvh_nodes, bvh.nodes.data(), sizeof(float4) * bvh.nodes.size()));
+            HIP_TRY(c, up(&c->d_bvh_spheres, bvh.spheres.data(), sizeof(float4) * bvh.spheres.size()));
+            HIP_TRY(c, up(&c->d_bvh_prim, bvh.prim.data(), sizeof(uint32_t) * bvh.prim.size()));
+            c->sc.bvh_nodes = (const float4 *)c->d_bvh_nodes;
+            c->sc.bvh_spheres = (const float4 *)c->d_bvh_spheres;
+            c->sc.bvh_prim = (const uint32_t *)c->d_bvh_prim;
+            c->sc.n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 2);
+            c->bvh_depth = bvh.depth;
+        }
+    }
     // scene class: only Lambertian BSDFs and only constant spectra -> the specialised kernels apply
     bool lc = true;
     for (uint32_t i = 0; i < s->n_bsdfs; i++) lc = lc && s->bsdfs[i].kind == IRIS_BSDF_LAMBERTIAN;

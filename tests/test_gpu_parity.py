@@ -94,10 +94,22 @@ def test_raygen_bit_exact(gpu, iris_trig, w, h, spp):
     assert np.array_equal(bits(d), bits(np.array([list(t.ray_d) for t in tr])))
 
 
-@pytest.mark.parametrize("scene_name", ["s1", "s3", "s2_small", "s2_chunked"])
-def test_intersect_bit_exact(gpu, iris_trig, scene_name):
+@pytest.fixture(scope="module")
+def gpu_list():
+    """A context that never builds a hierarchy: every scan tests every sphere, like scene.rs:116-166."""
+    import iris_amd
+    ctx = iris_amd.HipWavefront(device=0, bvh_min_prims=0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("scene_name,hierarchy", [("s1", True), ("s3", True), ("s2_small", True), ("s2_chunked", True),
+                                                  ("s2_small", False), ("s2_chunked", False)])
+def test_intersect_bit_exact(gpu, gpu_list, iris_trig, scene_name, hierarchy):
     """Scene::intersection (scene.rs:116-132): hit index (lowest index on ties) and t on identical rays,
-    including a list longer than the LDS window (s2_chunked) and rays from inside / grazing spheres."""
+    including a list longer than the LDS window (s2_chunked) and rays from inside / grazing spheres; through
+    the hierarchy (the default for more than 64 spheres) and through the list scans."""
+    gpu = gpu if hierarchy else gpu_list
     scene = make(scene_name)
     flat = gpu.upload(scene)
     osc = iris_trig.OracleScene(flat)
@@ -125,6 +137,33 @@ def test_intersect_tie_breaks_to_lowest_index(gpu, iris_trig):
     gpu.upload(sc)
     prim, t = gpu.dbg_intersect([[0, 0, 0]], [[0, 0, 1]])
     assert prim[0] == 0 and t[0] == 4.0
+
+
+def test_hierarchy_keeps_the_tie_rule_and_the_closest_hit(gpu, iris_trig):
+    """Many coincident and overlapping spheres scattered over the leaves of the hierarchy: the traversal visits
+    them in any order, yet the lowest index among equal t must win, exactly as the list scan decides."""
+    from iris_amd import ConstantSpectrum, LambertianBsdf, Scene, Sphere
+    rng = np.random.RandomState(9)
+    sc = Scene()
+    sc.add_emissive_material(Sphere((0.0, 9.0, 5.0), 1.0), LambertianBsdf(ConstantSpectrum(0.5)), ConstantSpectrum(1.0))
+    centres = rng.uniform(-3, 3, size=(40, 3)).astype(np.float32) + np.float32([0, 0, 8])
+    for k in range(400):  # every centre appears ten times, interleaved, with one of two radii
+        c = centres[k % 40]
+        sc.add_material(Sphere((float(c[0]), float(c[1]), float(c[2])), 0.75 if (k // 40) % 2 else 0.5), LambertianBsdf(ConstantSpectrum(0.5)))
+    flat = gpu.upload(sc)
+    osc = iris_trig.OracleScene(flat)
+    n = 4000
+    o = np.zeros((n, 3), np.float32)
+    o[n // 2:] = centres[rng.randint(0, 40, n - n // 2)]  # from inside the stacks of spheres
+    d = (centres[rng.randint(0, 40, n)] + rng.normal(0, 0.3, (n, 3))).astype(np.float32) - o
+    d[n // 2:] = rng.standard_normal((n - n // 2, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:8] = np.float32([[0, 0, 1], [0, 1, 0], [1, 0, 0], [0, 0, -1], [0, -1, 0], [-1, 0, 0], [0, 0.6, 0.8], [0.6, 0, 0.8]])  # axis-parallel rays
+    prim, t = gpu.dbg_intersect(o, d)
+    want = [osc.intersect(o[i], d[i])[:2] for i in range(n)]
+    assert prim.tolist() == [w[0] for w in want]
+    assert np.array_equal(bits(t), bits(np.array([w[1] for w in want])))
+    assert (prim >= 0).mean() > 0.5
 
 
 @pytest.mark.parametrize("scene_name,integrator,max_depth", [
@@ -190,7 +229,11 @@ def test_film_bit_exact(gpu, iris_trig, scene_name, w, h, spp, integrator, max_d
     assert np.array_equal(bits(film), bits(want))
     gs = gpu.stats()
     if max_depth > 0:
-        assert (gs.samples, gs.bounces, gs.rays, gs.sphere_tests) == (st.samples, st.bounces, st.rays, st.sphere_tests)
+        assert (gs.samples, gs.bounces, gs.rays) == (st.samples, st.bounces, st.rays)
+        if len(flat.spheres) <= 64:  # list scans: the oracle's count; with a hierarchy only the tests it makes
+            assert gs.sphere_tests == st.sphere_tests
+        else:
+            assert 0 < gs.sphere_tests < st.sphere_tests
 
 
 def test_film_matches_committed_golden(gpu):
@@ -310,17 +353,42 @@ def test_furnace_converges_on_gpu(gpu):
         assert abs(film[..., 1].mean() - 0.5) < 0.004, integrator
 
 
-def test_many_spheres_scene_counters(gpu, iris_trig):
-    """Config D geometry (10k spheres, streamed through the LDS window in chunks): a small film is
-    bit-exact against the oracle and every scan visits all 10 000 spheres."""
+def test_many_spheres_scene_counters(gpu, gpu_list, iris_trig):
+    """Config D geometry (10k spheres).  List scans (streamed through the LDS window in chunks): a small film
+    is bit-exact against the oracle and every scan visits all 10 000 spheres.  Hierarchy (the default): the
+    same film bit for bit, from a small fraction of the sphere tests, by the pool kernels and by the
+    register-resident kernel."""
+    import iris_amd
     from iris_amd import Render, Scene
     scene = Scene.many_spheres(10_000)
-    flat = gpu.upload(scene)
-    film = gpu.render_film(Render(40, 24, 2, scene))
+    flat = gpu_list.upload(scene)
+    film = gpu_list.render_film(Render(40, 24, 2, scene))
     want, st = oracle_film(iris_trig, flat, 40, 24, 2)
     assert np.array_equal(bits(film), bits(want))
-    gs = gpu.stats()
+    gs = gpu_list.stats()
     assert (gs.rays, gs.sphere_tests, gs.bounces) == (st.rays, st.sphere_tests, st.bounces)
+    gpu.upload(scene)
+    film_h = gpu.render_film(Render(40, 24, 2, scene))
+    assert np.array_equal(bits(film_h), bits(want))
+    gh = gpu.stats()
+    assert (gh.rays, gh.bounces) == (st.rays, st.bounces) and gh.sphere_tests < st.sphere_tests // 50
+    with iris_amd.HipWavefront(0, mode=2) as g2:
+        g2.upload(scene)
+        assert np.array_equal(bits(g2.render_film(Render(40, 24, 2, scene))), bits(want))
+        assert g2.stats().kernel == 2 and g2.stats().sphere_tests == gh.sphere_tests
+
+
+def test_list_scan_films_of_long_lists(gpu_list, iris_trig):
+    """The window-resident (600 spheres) and streamed (2500) list scans inside whole renders."""
+    from iris_amd import Render
+    for name in ("s2_small", "s2_chunked"):
+        scene = make(name)
+        flat = gpu_list.upload(scene)
+        film = gpu_list.render_film(Render(32, 24, 3, scene))
+        want, st = oracle_film(iris_trig, flat, 32, 24, 3)
+        assert np.array_equal(bits(film), bits(want))
+        gs = gpu_list.stats()
+        assert (gs.samples, gs.bounces, gs.rays, gs.sphere_tests) == (st.samples, st.bounces, st.rays, st.sphere_tests)
 
 
 # ---- error behaviour ---------------------------------------------------------------------------------
