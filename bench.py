@@ -133,7 +133,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config B per GPU: %s scene %dx%d, %d spp per GPU (%d spp total), HwssNaive, "
                                    "max_depth %d, spp-split + RCCL all-reduce of the XYZ film" %
-                                   ({"s1": "default (scene.rs:43-66, 3 spheres)", "s2": "10k-sphere", "s3": "glossy/dielectric"}[args.scene],
+                                   ({"s1": "default (scene.rs:43-66, 3 spheres)", "s2": "10k-sphere (hierarchy unless --opt bvh_min_prims=0)", "s3": "glossy/dielectric"}[args.scene],
                                     args.width, args.height, args.spp, spp_total, max_depth),
                        "width": args.width, "height": args.height, "spp_per_gpu": args.spp, "parallelism": "spp-split x%d" % world},
             # rank 0's path-tracing kernel, timed with HIP events on its own stream inside the library

@@ -162,9 +162,10 @@ const char *iris_last_error(const iris_ctx *ctx);
  *   "result_bytes"    cap on the per-sample result buffer (default 64 GiB)
  *   "multi_kernel"    1: launch the two stages as separate kernels (for profiling);
  *                     0: one persistent kernel (default)
- *   "mode"            0: choose by scene size (default); 1: pool/queue kernels (path state in HBM/L2,
- *                     rays compacted before every scan); 2: register-resident kernel (needs the
- *                     sphere list to fit the LDS window)
+ *   "mode"            0: choose by scene (default: register-resident kernel for up to 64 spheres and for scenes
+ *                     with a hierarchy, pool/queue kernels for longer lists scanned sphere by sphere);
+ *                     1: pool/queue kernels (path state in HBM/L2, rays compacted before every scan);
+ *                     2: register-resident kernel (needs the sphere list to fit the LDS window, or a hierarchy)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 32)
  *   "bvh_min_prims"   scenes with at least this many spheres get a bounding-volume hierarchy at upload and the
  *                     scans traverse it (default 65; 0 = never: every scan tests every sphere like scene.rs:116-166).

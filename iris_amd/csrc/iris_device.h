@@ -431,6 +431,7 @@ struct SceneDev {
     const float4 *bvh_spheres;   // (cx, cy, cz, r * r) in leaf order
     const uint32_t *bvh_prim;    // primitive index of each leaf-ordered sphere
     uint32_t n_bvh_nodes;
+    uint32_t bvh_big_first, bvh_big_count;  // leaf-ordered spheres kept out of the tree (scene-sized ones): tested first
 };
 
 // shape/mod.rs:14-38
@@ -530,30 +531,43 @@ IRIS_DEV float box_entry(float4 lo, float4 hi, V3 o, V3 inv, float closest_t) {
     float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));
     return (tmin <= tmax && tmin <= closest_t) ? tmin : __builtin_inff();  // inf: do not enter
 }
+// one leaf-ordered sphere, with the tie rule on the primitive index (visiting order is not index order)
+IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, float &closest_t, int &closest) {
+    const float4 sp4 = sc.bvh_spheres[slot];
+    const int index = (int)sc.bvh_prim[slot];
+    V3 oc = ray.o - v3(sp4.x, sp4.y, sp4.z);
+    float half_b = dot(ray.d, oc);
+    float c = len_squared(oc) - sp4.w;
+    float discrim = half_b * half_b - a * c;
+    if (discrim > 0.0f) {  // sphere.rs:31-35, :53
+        float root = rsqrt_exact(discrim);
+        float temp = (-half_b - root) / a;
+        if (!(temp > 0.0f)) temp = (-half_b + root) / a;
+        if (temp > 0.0f && (temp < closest_t || (temp == closest_t && index < closest))) { closest_t = temp; closest = index; }
+    }
+}
+// A node reference is its (first, count) pair packed into one word: count (0 = inner node) in the top three
+// bits.  References come out of the fetch that tested the node's box, so a node's own record is never read
+// again; a stacked reference whose subtree a later hit has made unreachable fails its children's box tests.
+IRIS_DEV uint32_t bvh_ref(float4 lo, float4 hi) { return __float_as_uint(lo.w) | (__float_as_uint(hi.w) << 29); }
 IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests) {
     const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-    uint32_t sp = 0u, node = 0u;
-    uint32_t n_tests = 0u;
-    if (!(box_entry(sc.bvh_nodes[0], sc.bvh_nodes[1], ray.o, inv, closest_t) < __builtin_inff())) return;
+    uint32_t n_tests = sc.bvh_big_count;
+    for (uint32_t k = 0; k < sc.bvh_big_count; k++) bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
+    const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
+    uint32_t ref = bvh_ref(root_lo, root_hi);
+    uint32_t sp = 0u;
+    bool have = box_entry(root_lo, root_hi, ray.o, inv, closest_t) < __builtin_inff();
     for (;;) {
-        const float4 n0 = sc.bvh_nodes[2u * node], n1 = sc.bvh_nodes[2u * node + 1u];
-        const uint32_t first = __float_as_uint(n0.w), count = __float_as_uint(n1.w);
-        bool pop = true;
+        if (!have) {
+            if (sp == 0u) break;
+            sp--;
+            ref = stack[sp * IRIS_BLOCK];
+        }
+        have = false;
+        const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
         if (count != 0u) {
-            for (uint32_t k = 0; k < count; k++) {
-                const float4 sp4 = sc.bvh_spheres[first + k];
-                const int index = (int)sc.bvh_prim[first + k];
-                V3 oc = ray.o - v3(sp4.x, sp4.y, sp4.z);
-                float half_b = dot(ray.d, oc);
-                float c = len_squared(oc) - sp4.w;
-                float discrim = half_b * half_b - a * c;
-                if (discrim > 0.0f) {  // sphere.rs:31-35, :53
-                    float root = rsqrt_exact(discrim);
-                    float temp = (-half_b - root) / a;
-                    if (!(temp > 0.0f)) temp = (-half_b + root) / a;
-                    if (temp > 0.0f && (temp < closest_t || (temp == closest_t && index < closest))) { closest_t = temp; closest = index; }
-                }
-            }
+            for (uint32_t k = 0; k < count; k++) bvh_sphere_test(sc, first + k, ray, a, closest_t, closest);
             n_tests += count;
         } else {
             const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
@@ -561,19 +575,15 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, f
             const float tl = box_entry(l0, l1, ray.o, inv, closest_t), tr = box_entry(r0, r1, ray.o, inv, closest_t);
             const bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
             if (hl || hr) {
-                pop = false;
                 const bool left_first = hl && (!hr || tl <= tr);
-                node = left_first ? first : first + 1u;
+                const uint32_t ref_l = bvh_ref(l0, l1), ref_r = bvh_ref(r0, r1);
                 if (hl && hr) {  // the farther child waits on the stack (depth <= IRIS_BVH_STACK by construction)
-                    stack[sp * IRIS_BLOCK] = left_first ? first + 1u : first;
+                    stack[sp * IRIS_BLOCK] = left_first ? ref_r : ref_l;
                     sp++;
                 }
+                ref = left_first ? ref_l : ref_r;
+                have = true;
             }
-        }
-        if (pop) {
-            if (sp == 0u) break;
-            sp--;
-            node = stack[sp * IRIS_BLOCK];
         }
     }
     tests += n_tests;
