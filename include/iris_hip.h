@@ -73,6 +73,20 @@ typedef struct { uint32_t kind; uint32_t spec_a, spec_b; float p0, p1; } iris_bs
 /* scene.rs:24: lights: Vec<PrimIndex<Spectrum>> (types.rs:1-5) */
 typedef struct { uint32_t spectrum; uint32_t prim; } iris_light;
 
+/* Scene._env_map: Vec<UpsampledHdrSpectrum> (scene.rs:27).  The reference declares the field, never fills it
+ * (background_emission returns 0, scene.rs:112-114) and notes that it is not importance-sampled yet
+ * (upsample.rs:53-54); what the map looks like and how it is sampled is therefore this build's definition
+ * (docs/SPEC.md section 6): width*height texels of UpsampledHdrSpectrum as (c0, c1, c2, hdr_coefficient),
+ * row-major, in the OCTAHEDRAL layout (square [-1,1]^2 folded onto the sphere, y = pole axis: direction ->
+ * texel needs one division and no inverse trigonometry, and texel solid angles vary by 5.2x at most).
+ * importance: width*height non-negative weights (e.g. luminance) the sampling CDFs are built from, times
+ * each texel's solid angle; NULL = the texel's hdr_coefficient. */
+typedef struct {
+    uint32_t width, height;
+    const float *texels;
+    const float *importance;
+} iris_envmap_desc;
+
 /* Flattened `Scene` (scene.rs:22-28).  prim_material[i] / prim_light[i] are
  * Primitive::material_index / light_index (shape/mod.rs:55-60), -1 for None.
  * Primitive order is the order of the reference's `primitives` Vec: the
@@ -88,6 +102,7 @@ typedef struct {
     const iris_spectrum *spectra;
     uint32_t n_lights;
     const iris_light *lights;
+    const iris_envmap_desc *env_map; /* NULL: none (the reference's behaviour: a ray that leaves the scene carries nothing) */
 } iris_scene_desc;
 
 /* camera.rs:3-7; matrices row-major (m[i][j] at 4*i+j) */
@@ -200,6 +215,23 @@ void iris_upsample_table_free(iris_upsample_table *table);
 uint32_t iris_upsample_table_resolution(const iris_upsample_table *table);
 int iris_upsample_get_spectrum(const iris_upsample_table *table, const float rgb[3], iris_spectrum *out);
 int iris_upsample_get_spectrum_hdr(const iris_upsample_table *table, const float rgb[3], iris_spectrum *out);
+
+/* Environment-map helpers (host side, used while a scene is built; docs/SPEC.md section 6).
+ * iris_envmap_tables: the sampling tables iris_scene_upload builds from a map -- func[w*h] (importance x
+ *   texel solid-angle weight), cond_cdf[(w+1)*h] (per row), marg_cdf[h+1], *integral -- for inspection and
+ *   parity tests.
+ * iris_oct_to_dir / iris_dir_to_oct: the octahedral mapping itself ((u,v) in [-1,1]^2 <-> unit direction).
+ * iris_envmap_from_latlong: resamples an equirectangular RGB image (row 0 = +y pole, column 0 = direction -z,
+ *   turning towards +x) to the octahedral layout, bilinear, at texel centres.
+ * iris_envmap_texels_from_rgb: per texel UpsampleTable::get_spectrum_hdr (upsample.rs:46-56) with its clamp
+ *   of the HDR factor at `max_hdr` (the reference: 50, "until we importance sample the env map"; INFINITY:
+ *   none) -> texels[4*n]; importance[n] (may be NULL) = Rec.709 luminance of the RGB value. */
+int iris_envmap_tables(const iris_envmap_desc *map, float *func, float *cond_cdf, float *marg_cdf, float *integral);
+void iris_oct_to_dir(float u, float v, float dir[3]);
+void iris_dir_to_oct(const float dir[3], float uv[2]);
+int iris_envmap_from_latlong(const float *rgb, uint32_t width, uint32_t height, uint32_t out_width, uint32_t out_height, float *out_rgb);
+int iris_envmap_texels_from_rgb(const iris_upsample_table *table, const float *rgb, size_t n_texels, float max_hdr,
+                                float *texels, float *importance);
 
 /* ---- the hot path ----------------------------------------------------- */
 

@@ -11,6 +11,6 @@ The compute path is libiris_hip.so (hand-written HIP); there is no CPU fallback.
 from .ffi import IrisError  # noqa: F401
 from .render import Camera, HipWavefront, Render, film_to_rgb  # noqa: F401
 from .scene import (  # noqa: F401
-    HWSS_NAIVE, HWSS_SLOW, SWSS_NAIVE, SWSS_SLOW, INTEGRATORS, ConstantSpectrum, FresnelBsdf, LambertianBsdf,
+    HWSS_NAIVE, HWSS_SLOW, SWSS_NAIVE, SWSS_SLOW, INTEGRATORS, ConstantSpectrum, EnvMap, FresnelBsdf, LambertianBsdf,
     MicrofacetBsdf, NullBsdf, Scene, SpecularBsdf, Sphere, UpsampledHdrSpectrum, UpsampledSpectrum, UpsampleTable,
 )

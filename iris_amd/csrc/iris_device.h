@@ -432,6 +432,14 @@ struct SceneDev {
     const uint32_t *bvh_prim;    // primitive index of each leaf-ordered sphere
     uint32_t n_bvh_nodes;
     uint32_t bvh_big_first, bvh_big_count;  // leaf-ordered spheres kept out of the tree (scene-sized ones): tested first
+    // Environment map (docs/SPEC.md section 6; env_w == 0: none): octahedral layout, one float4 per texel
+    // (c0, c1, c2, hdr_coefficient) = UpsampledHdrSpectrum; sampling tables built at upload.
+    const float4 *env_texels;
+    const float *env_func;      // importance x texel solid-angle weight
+    const float *env_cond_cdf;  // env_w + 1 per row
+    const float *env_marg_cdf;  // env_h + 1
+    uint32_t env_w, env_h;
+    float env_integral;
 };
 
 // shape/mod.rs:14-38
@@ -805,6 +813,59 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
     // IRIS_BSDF_NULL (null.rs: unreachable!()): absorbs
 }
 
+// ---------------------------------------------------------------- environment map (docs/SPEC.md section 6)
+// The reference stubs it (Scene._env_map scene.rs:27, background_emission scene.rs:112-114, the clamp note of
+// upsample.rs:53-54); layout, look-up and sampling are this build's definition.  Octahedral square, y = pole
+// axis: only + - * / sqrt and compares, so GPU and CPU agree to the bit without an inverse-trigonometry spec.
+IRIS_DEV float env_sgn(float a) { return a >= 0.0f ? 1.0f : -1.0f; }
+IRIS_DEV V3 oct_point(float u, float v) {
+    float y = (1.0f - fabs_(u)) - fabs_(v);
+    if (y >= 0.0f) return v3(u, y, v);
+    return v3((1.0f - fabs_(v)) * env_sgn(u), y, (1.0f - fabs_(u)) * env_sgn(v));
+}
+IRIS_DEV uint32_t env_texel_coord(float t, uint32_t n) {
+    uint32_t i = f_as_index((t * 0.5f + 0.5f) * (float)n);
+    return i < n ? i : n - 1u;
+}
+// Emission arriving along direction d (the four wavelengths) and the solid-angle density with which
+// env_sample produces d.
+IRIS_DEV void env_eval(const SceneDev &sc, V3 d, F4 wl, F4 &le, float &pdf) {
+    float s = (fabs_(d.x) + fabs_(d.y)) + fabs_(d.z);
+    V3 q = v3(d.x / s, d.y / s, d.z / s);
+    float u, v;
+    if (q.y >= 0.0f) { u = q.x; v = q.z; }
+    else { u = (1.0f - fabs_(q.z)) * env_sgn(q.x); v = (1.0f - fabs_(q.x)) * env_sgn(q.z); }
+    float l2 = len_squared(q);
+    float jac = l2 * rsqrt_exact(l2);  // |q|^3: d(omega) = du dv / |q|^3
+    uint32_t c = env_texel_coord(u, sc.env_w), r = env_texel_coord(v, sc.env_h);
+    uint32_t idx = r * sc.env_w + c;
+    float4 t = sc.env_texels[idx];
+    iris_spectrum sp = {IRIS_SPEC_UPSAMPLED_HDR, t.x, t.y, t.z, t.w};
+    le = spectrum_evaluate(sp, wl, false);
+    pdf = sc.env_integral > 0.0f ? ((sc.env_func[idx] / sc.env_integral) * 0.25f) * jac : 0.0f;
+}
+// Piecewise-constant 1-D distribution: the largest idx with cdf[idx] <= u by bisection ("CDF search"),
+// then the continuous position inside that bin, in [0, 1].
+IRIS_DEV float env_sample_1d(const float *cdf, uint32_t n, float u, uint32_t &idx) {
+    uint32_t lo = 0u, hi = n;
+    while (hi - lo > 1u) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid; else hi = mid;
+    }
+    float c0 = cdf[lo], c1 = cdf[lo + 1u];
+    float den = c1 - c0;
+    float du = u - c0;
+    if (den > 0.0f) du = du / den;
+    idx = lo;
+    return ((float)lo + du) / (float)n;
+}
+IRIS_DEV V3 env_sample(const SceneDev &sc, float u0, float u1) {
+    uint32_t r, c;
+    float vv = env_sample_1d(sc.env_marg_cdf, sc.env_h, u0, r);
+    float uu = env_sample_1d(sc.env_cond_cdf + (size_t)r * (sc.env_w + 1u), sc.env_w, u1, c);
+    return normalize(oct_point(2.0f * uu - 1.0f, 2.0f * vv - 1.0f));
+}
+
 // ---------------------------------------------------------------- path state and the two stages' per-lane work
 struct Counters { uint32_t samples, bounces, rays; unsigned long long sphere_tests; };
 
@@ -883,6 +944,25 @@ IRIS_DEV V3 path_xyz(const PathState &ps) {
 // Same operations in the same order on the same values either way: the film does not change by a bit.
 #define IRIS_CLS_GENERAL 0
 #define IRIS_CLS_LAMBERT_CONSTANT 1
+#define IRIS_CLS_GENERAL_ENV 2  // IRIS_CLS_GENERAL plus the environment-map code (used when sc.env_w != 0)
+template <int CLS>
+IRIS_DEV bool env_on(const SceneDev &sc) { return CLS == IRIS_CLS_GENERAL_ENV && sc.env_w != 0u; }
+
+// A ray that left the scene: `None => break` (hwss_naive.rs:41-44).  With an environment map the map's
+// emission is added under the rule the integrator has for emitters it hits (after the commented miss branch
+// of scene.rs:351-353): at bounce 0 only with next-event estimation, at every bounce without.
+template <int INTEG, int CLS>
+IRIS_DEV void path_miss(const SceneDev &sc, PathState &ps) {
+    constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
+    constexpr bool NAIVE = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_SWSS_NAIVE);
+    if (!env_on<CLS>(sc)) return;
+    if (NAIVE && ps.bounce != 0u) return;
+    F4 le;
+    float pdf_unused;
+    env_eval(sc, ps.ray.d, wavelength_new(ps.hero_nm), le, pdf_unused);
+    if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
+    else ps.rad = ps.rad + ps.thr * le;
+}
 template <int INTEG, int CLS>
 IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, DrawRing ring, bool active,
                            PathState &ps, int prim, float t, Counters &cnt) {
@@ -934,28 +1014,53 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         V3 light_pos = v3(0.0f, 0.0f, 0.0f);
         float light_pdf = 0.0f;
         bool want1 = false;
+        // With an environment map the map is entry n_lights of the light list (docs/SPEC.md section 6); its two
+        // strategies mirror the sphere light's: a direction from the map's CDFs (2 draws, as Sphere::sample)
+        // that must reach nothing, and the BSDF-sampled ray counted when it leaves the scene.  light_prim
+        // stays -1 for it, which is what a scan that hits nothing reports.
+        const bool ENV = env_on<CLS>(sc);
+        bool env_pick = false;
         if (alive) {
             // scene.rs:168-172 + sampler.rs:52-60
+            const uint32_t n_total = sc.n_lights + (ENV ? 1u : 0u);
             float u = gen_0_1(ring, ps.smp);
-            uint32_t light_idx = f_as_index(u * (((float)sc.n_lights - 0.5f) - 0.0f) + 0.0f);
-            if (light_idx >= sc.n_lights) light_idx = sc.n_lights - 1u;  // never taken for u in [0, 1); keeps a bad draw from indexing out of bounds
-            iris_light l = sc.lights[light_idx];
-            light_prim = (int)l.prim;
-            light_pick_weight = (float)sc.n_lights;
-            light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl, MONO);
-            light_sphere = sc.spheres[light_prim];
-            sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf);
-            shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
-            bool facing_forward = dot(light_pos - hit.point, hit.normal) > 0.0f;
-            want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
+            uint32_t light_idx = f_as_index(u * (((float)n_total - 0.5f) - 0.0f) + 0.0f);
+            if (light_idx >= n_total) light_idx = n_total - 1u;  // never taken for u in [0, 1); keeps a bad draw from indexing out of bounds
+            light_pick_weight = (float)n_total;
+            bool facing_forward;
+            if (ENV && light_idx >= sc.n_lights) {
+                env_pick = true;
+                float u0 = gen_0_1(ring, ps.smp);
+                float u1 = gen_0_1(ring, ps.smp);
+                V3 dir = env_sample(sc, u0, u1);
+                shadow1 = ray_spawn(hit.point, dir, hit.normal);
+                env_eval(sc, shadow1.d, wl, light_emission, light_pdf);
+                facing_forward = dot(dir, hit.normal) > 0.0f;
+                want1 = light_pdf > 0.0f && facing_forward != hit.back_face;
+            } else {
+                iris_light l = sc.lights[light_idx];
+                light_prim = (int)l.prim;
+                light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl, MONO);
+                light_sphere = sc.spheres[light_prim];
+                sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf);
+                shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
+                facing_forward = dot(light_pos - hit.point, hit.normal) > 0.0f;
+                want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
+            }
         }
         float st1;
         int sp1;
         scan_closest(sc, st, want1, shadow1, st1, sp1, cnt.sphere_tests);  // scene.rs:134-149
         if (want1) {
             cnt.rays++;
-            float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
-            if (st1 > target_t - IRIS_RAY_EPSILON) {
+            bool visible;
+            if (ENV && env_pick) {
+                visible = sp1 < 0;
+            } else {
+                float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
+                visible = st1 > target_t - IRIS_RAY_EPSILON;
+            }
+            if (visible) {
                 V3 shading_wi = world_to_shading(hit, shadow1.d);
                 F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl, MONO);
                 F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
@@ -982,7 +1087,9 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         if (want2) {
             cnt.rays++;
             if (sp2 == light_prim) {
-                float lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
+                float lpdf;
+                if (ENV && env_pick) env_eval(sc, shadow2.d, wl, light_emission, lpdf);
+                else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
                 float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : hero(bs_pdfs) / (hero(bs_pdfs) + lpdf);
                 direct = direct + (((mis_weight * light_emission) * bs_values) * bs_cos) / hero(bs_pdfs);
             }

@@ -243,3 +243,115 @@ int iris_upsample_get_spectrum_hdr(const iris_upsample_table *t, const float rgb
 }
 
 }  // extern "C"
+
+// ---- environment map, host side (docs/SPEC.md section 6; the reference only stubs it: scene.rs:27, :112-114) ----
+namespace {
+
+float env_sgn(float a) { return a >= 0.0f ? 1.0f : -1.0f; }
+// octahedral square [-1,1]^2 -> point on the octahedron |x|+|y|+|z| = 1 (y = pole axis)
+void oct_point(float u, float v, float q[3]) {
+    const float y = (1.0f - std::fabs(u)) - std::fabs(v);
+    if (y >= 0.0f) { q[0] = u; q[1] = y; q[2] = v; }
+    else { q[0] = (1.0f - std::fabs(v)) * env_sgn(u); q[1] = y; q[2] = (1.0f - std::fabs(u)) * env_sgn(v); }
+}
+// cdf[0..n] of n non-negative values, accumulated in binary64; returns their mean
+double build_cdf(const float *func, uint32_t n, float *cdf) {
+    double acc = 0.0;
+    for (uint32_t i = 0; i < n; i++) acc += (double)func[i];
+    double run = 0.0;
+    cdf[0] = 0.0f;
+    for (uint32_t i = 1; i <= n; i++) {
+        run += (double)func[i - 1];
+        cdf[i] = acc > 0.0 ? (float)(run / acc) : (float)i / (float)n;
+    }
+    cdf[n] = 1.0f;
+    return acc / (double)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int iris_envmap_tables(const iris_envmap_desc *m, float *func, float *cond_cdf, float *marg_cdf, float *integral) {
+    if (!m || !m->texels || m->width == 0 || m->height == 0 || !func || !cond_cdf || !marg_cdf || !integral) return IRIS_E_ARG;
+    const uint32_t w = m->width, h = m->height;
+    std::vector<float> row_mean(h);
+    for (uint32_t r = 0; r < h; r++) {
+        for (uint32_t c = 0; c < w; c++) {
+            const float u = (((float)c + 0.5f) / (float)w) * 2.0f - 1.0f;
+            const float v = (((float)r + 0.5f) / (float)h) * 2.0f - 1.0f;
+            float q[3];
+            oct_point(u, v, q);
+            const float l2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+            const size_t i = (size_t)r * w + c;
+            float imp = m->importance ? m->importance[i] : m->texels[4 * i + 3];
+            if (!(imp > 0.0f)) imp = 0.0f;  // negative or NaN importance: never sampled
+            func[i] = imp / (l2 * std::sqrt(l2));  // 1 / |q|^3: the texel's solid angle up to a constant
+        }
+        row_mean[r] = (float)build_cdf(func + (size_t)r * w, w, cond_cdf + (size_t)r * (w + 1));
+    }
+    *integral = (float)build_cdf(row_mean.data(), h, marg_cdf);
+    return IRIS_OK;
+}
+
+void iris_oct_to_dir(float u, float v, float dir[3]) {
+    float q[3];
+    oct_point(u, v, q);
+    const float len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    dir[0] = q[0] / len; dir[1] = q[1] / len; dir[2] = q[2] / len;
+}
+
+void iris_dir_to_oct(const float d[3], float uv[2]) {
+    const float s = (std::fabs(d[0]) + std::fabs(d[1])) + std::fabs(d[2]);
+    const float qx = d[0] / s, qy = d[1] / s, qz = d[2] / s;
+    if (qy >= 0.0f) { uv[0] = qx; uv[1] = qz; }
+    else { uv[0] = (1.0f - std::fabs(qz)) * env_sgn(qx); uv[1] = (1.0f - std::fabs(qx)) * env_sgn(qz); }
+}
+
+int iris_envmap_from_latlong(const float *rgb, uint32_t w, uint32_t h, uint32_t ow, uint32_t oh, float *out) {
+    if (!rgb || !out || w == 0 || h == 0 || ow == 0 || oh == 0) return IRIS_E_ARG;
+    const double PI = 3.14159265358979323846;
+    for (uint32_t r = 0; r < oh; r++) {
+        for (uint32_t c = 0; c < ow; c++) {
+            float d[3];
+            iris_oct_to_dir((((float)c + 0.5f) / (float)ow) * 2.0f - 1.0f, (((float)r + 0.5f) / (float)oh) * 2.0f - 1.0f, d);
+            const double theta = std::acos(std::max(-1.0, std::min(1.0, (double)d[1])));  // 0 at +y
+            double phi = std::atan2((double)d[0], -(double)d[2]);                           // 0 at -z, towards +x
+            if (phi < 0.0) phi += 2.0 * PI;
+            const double fx = phi / (2.0 * PI) * w - 0.5, fy = theta / PI * h - 0.5;
+            const double x0f = std::floor(fx), y0f = std::floor(fy);
+            const double ax = fx - x0f, ay = fy - y0f;
+            const long x0 = (long)x0f, y0 = (long)y0f;
+            for (int k = 0; k < 3; k++) {
+                double acc = 0.0;
+                for (int dy = 0; dy < 2; dy++) {
+                    for (int dx = 0; dx < 2; dx++) {
+                        const long xx = ((x0 + dx) % (long)w + (long)w) % (long)w;       // longitude wraps
+                        const long yy = std::max(0l, std::min((long)h - 1, y0 + dy));  // latitude clamps
+                        acc += (dx ? ax : 1.0 - ax) * (dy ? ay : 1.0 - ay) * (double)rgb[3 * ((size_t)yy * w + xx) + k];
+                    }
+                }
+                out[3 * ((size_t)r * ow + c) + k] = (float)acc;
+            }
+        }
+    }
+    return IRIS_OK;
+}
+
+int iris_envmap_texels_from_rgb(const iris_upsample_table *t, const float *rgb, size_t n, float max_hdr, float *texels, float *importance) {
+    if (!t || !rgb || !texels) return IRIS_E_ARG;
+    for (size_t i = 0; i < n; i++) {
+        const float *p = rgb + 3 * i;
+        // UpsampleTable::get_spectrum_hdr, upsample.rs:46-56, with the clamp as a parameter
+        const float max = rust_max(rust_max(rust_max(p[0], p[1]), p[2]), 1.0f);
+        const float nrm[3] = {p[0] / max, p[1] / max, p[2] / max};
+        float c[3];
+        get_spectrum(*t, nrm, c);
+        texels[4 * i] = c[0]; texels[4 * i + 1] = c[1]; texels[4 * i + 2] = c[2];
+        texels[4 * i + 3] = rust_min(max, max_hdr);
+        if (importance) importance[i] = 0.2126f * p[0] + 0.7152f * p[1] + 0.0722f * p[2];
+    }
+    return IRIS_OK;
+}
+
+}  // extern "C"

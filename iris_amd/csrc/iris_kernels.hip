@@ -131,7 +131,7 @@ __device__ __forceinline__ void flush_counters(const WfArgs &a, const Counters &
 __device__ __forceinline__ unsigned long long item_of(const WfArgs &a, uint32_t k);
 
 // ---- stage A: refill dead slots, generate camera rays, closest hit, compact hits into the queue ----
-template <int INTEG>
+template <int INTEG, int CLS>
 __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereStage &st, SobolLds tab, DrawRing ring, BlockShared &bs, Counters &cnt) {
     const uint32_t slot0 = blockIdx.x * a.slots_per_block;
     for (uint32_t tile = 0; tile < a.slots_per_block; tile += BLOCK) {
@@ -169,10 +169,23 @@ __device__ __forceinline__ void stage_gen_extend(const WfArgs &a, const SphereSt
         const bool hitp = active && prim >= 0;
         if (active && !hitp) {  // the path left the scene: `None => break` (hwss_naive.rs:41-44)
             if (regen) {
-                store_result(a, item, v3(0.0f, 0.0f, 0.0f));  // radiance is still exactly zero
+                if (env_on<CLS>(a.sc)) {
+                    path_miss<INTEG, CLS>(a.sc, ps);
+                    store_result(a, item, path_xyz<INTEG>(ps));
+                } else {
+                    store_result(a, item, v3(0.0f, 0.0f, 0.0f));  // radiance is still exactly zero
+                }
             } else {
                 float4 r = a.pool.rad[slot];
                 ps.rad = f4(r.x, r.y, r.z, r.w);
+                if (env_on<CLS>(a.sc)) {
+                    float4 th = a.pool.thr[slot];
+                    ps.thr = f4(th.x, th.y, th.z, th.w);
+                    if (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW) { float4 pp = a.pool.ppdf[slot]; ps.ppdf = f4(pp.x, pp.y, pp.z, pp.w); }
+                    else ps.ppdf = splat(1.0f);
+                    ps.bounce = __float_as_uint(rd.w) & 0xffffu;
+                    path_miss<INTEG, CLS>(a.sc, ps);
+                }
                 store_result(a, a.pool.meta[slot].z, path_xyz<INTEG>(ps));
                 rd.w = __uint_as_float(0u);
                 a.pool.rayd[slot] = rd;
@@ -280,7 +293,7 @@ k_wavefront(WfArgs a) {
     __syncthreads();
     Counters cnt = {0u, 0u, 0u, 0u};
     for (;;) {
-        stage_gen_extend<INTEG>(a, st, sobol_lds, ring, bs, cnt);
+        stage_gen_extend<INTEG, CLS>(a, st, sobol_lds, ring, bs, cnt);
         __syncthreads();
         const uint32_t qn = bs.qn;
         const bool more = bs.cursor < bs.w_end;
@@ -356,6 +369,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                     if (prim >= 0) {
                         lane_state = LANE_HIT;
                     } else {  // `None => break` (hwss_naive.rs:41-44)
+                        path_miss<INTEG, CLS>(a.sc, ps);
                         store_result(a, item, path_xyz<INTEG>(ps));
                         lane_state = LANE_DEAD;
                     }
@@ -387,7 +401,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             scan_closest(a.sc, st, valid, ray, t_new, prim_new, cnt.sphere_tests);
             if (valid) {
                 cnt.rays++;
-                if (prim_new < 0) store_result(a, new_item, v3(0.0f, 0.0f, 0.0f));  // radiance is exactly zero: `None => break`
+                if (prim_new < 0) {  // `None => break`
+                    if (env_on<CLS>(a.sc)) {
+                        PathState pm;
+                        pm.ray = ray; pm.hero_nm = cs.hero_nm; pm.bounce = 0u;
+                        pm.thr = splat(1.0f); pm.ppdf = splat(1.0f); pm.rad = splat(0.0f);
+                        path_miss<INTEG, CLS>(a.sc, pm);
+                        store_result(a, new_item, path_xyz<INTEG>(pm));
+                    } else {
+                        store_result(a, new_item, v3(0.0f, 0.0f, 0.0f));  // radiance is exactly zero
+                    }
+                }
             }
             const bool hitp = valid && prim_new >= 0;
             const unsigned long long hmask = __ballot(hitp);
@@ -468,7 +492,7 @@ __global__ void __launch_bounds__(BLOCK) k_stage_gen_extend(WfArgs a) {
     }
     __syncthreads();
     Counters cnt = {0u, 0u, 0u, 0u};
-    stage_gen_extend<INTEG>(a, st, sobol_lds, ring, bs, cnt);
+    stage_gen_extend<INTEG, IRIS_CLS_GENERAL_ENV>(a, st, sobol_lds, ring, bs, cnt);
     __syncthreads();
     if (threadIdx.x == 0) {
         a.blk_cursor[blockIdx.x] = bs.cursor < bs.w_end ? bs.cursor : bs.w_end;
@@ -489,7 +513,7 @@ __global__ void __launch_bounds__(BLOCK) k_stage_shade(WfArgs a) {
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
     __syncthreads();
     Counters cnt = {0u, 0u, 0u, 0u};
-    stage_shade<INTEG, IRIS_CLS_GENERAL>(a, st, sobol_lds, ring, qn, cnt);
+    stage_shade<INTEG, IRIS_CLS_GENERAL_ENV>(a, st, sobol_lds, ring, qn, cnt);
     flush_counters(a, cnt);
 }
 
@@ -585,12 +609,15 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, Fr
         float t;
         int prim;
         scan_closest(sc, st, alive, ps.ray, t, prim, cnt.sphere_tests);
-        if (alive && prim < 0) alive = false;
+        if (alive && prim < 0) {
+            path_miss<INTEG, IRIS_CLS_GENERAL_ENV>(sc, ps);
+            alive = false;
+        }
         if (alive) {
             if (n_hits < IRIS_TRACE_MAX_DEPTH) { tr->hit_prim[n_hits] = prim; tr->hit_t[n_hits] = t; }
             n_hits++;
         }
-        alive = shade_bounce<INTEG, IRIS_CLS_GENERAL>(sc, st, fr, sobol_lds, ring, alive, ps, prim, t, cnt);
+        alive = shade_bounce<INTEG, IRIS_CLS_GENERAL_ENV>(sc, st, fr, sobol_lds, ring, alive, ps, prim, t, cnt);
     }
     if (tr) {
         V3 xyz = path_xyz<INTEG>(ps);
@@ -628,6 +655,7 @@ struct iris_ctx {
     SceneDev sc = {};
     void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr;
     void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr;
+    void *d_env_texels = nullptr, *d_env_func = nullptr, *d_env_cond = nullptr, *d_env_marg = nullptr;
     uint32_t bvh_depth = 0;
     // pools
     uint32_t pool_blocks = 0, pool_slots_per_block = 0;
@@ -873,7 +901,7 @@ int check_scene_for(iris_ctx *ctx, const iris_render_params *p) {
     if (!ctx->have_scene) return fail(ctx, IRIS_E_STATE, "no scene uploaded");
     bool naive = p->integrator == IRIS_INT_HWSS_NAIVE || p->integrator == IRIS_INT_SWSS_NAIVE;
     // pick_one_light on an empty light list indexes out of bounds in the reference (scene.rs:168-172)
-    if (naive && ctx->sc.n_lights == 0) return fail(ctx, IRIS_E_ARG, "next-event estimation needs at least one light");
+    if (naive && ctx->sc.n_lights == 0 && ctx->sc.env_w == 0) return fail(ctx, IRIS_E_ARG, "next-event estimation needs at least one light");
     return IRIS_OK;
 }
 FrameDev frame_dev(const iris_render_params *p) {
@@ -905,16 +933,19 @@ int pool_blocks_per_cu(const iris_ctx *c, size_t dyn_lds) {
     int n = 0;
     hipError_t e = c->scene_class == IRIS_CLS_LAMBERT_CONSTANT
                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wavefront<INTEG, IRIS_CLS_LAMBERT_CONSTANT>, BLOCK, dyn_lds)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wavefront<INTEG, IRIS_CLS_GENERAL>, BLOCK, dyn_lds);
+                       : (c->scene_class == IRIS_CLS_GENERAL_ENV
+                              ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wavefront<INTEG, IRIS_CLS_GENERAL_ENV>, BLOCK, dyn_lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_wavefront<INTEG, IRIS_CLS_GENERAL>, BLOCK, dyn_lds));
     return (e == hipSuccess && n >= 1) ? n : 2;
 }
 
 template <int INTEG>
 int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stream) {
     size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
-    const bool lc = c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;
+    const bool lc = c->scene_class == IRIS_CLS_LAMBERT_CONSTANT, env = c->scene_class == IRIS_CLS_GENERAL_ENV;
     if (use_register_kernel(c)) {
         if (lc) hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_LAMBERT_CONSTANT>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        else if (env) hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_GENERAL_ENV>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
         else hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_GENERAL>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
         HIP_TRY(c, hipGetLastError());
         c->stats.launches += 1;
@@ -922,6 +953,7 @@ int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stre
     }
     if (!c->multi_kernel) {
         if (lc) hipLaunchKernelGGL((k_wavefront<INTEG, IRIS_CLS_LAMBERT_CONSTANT>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        else if (env) hipLaunchKernelGGL((k_wavefront<INTEG, IRIS_CLS_GENERAL_ENV>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
         else hipLaunchKernelGGL((k_wavefront<INTEG, IRIS_CLS_GENERAL>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
         HIP_TRY(c, hipGetLastError());
         c->stats.launches += 1;
@@ -1084,6 +1116,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     free_pools(c);
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
+    dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1116,7 +1149,8 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
         c->bvh_min_prims = value;  // takes effect at the next iris_scene_upload
     } else if (k == "specialize") {
         c->specialize = value ? 1 : 0;
-        c->scene_class = (c->specialize && c->scene_is_lambert_constant) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL;
+        if (c->scene_class != IRIS_CLS_GENERAL_ENV)
+            c->scene_class = (c->specialize && c->scene_is_lambert_constant) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL;
     } else if (k == "reg_blocks_per_cu") {
         if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "reg_blocks_per_cu out of range [1, 1024]");
         c->reg_blocks_per_cu = value;
@@ -1149,9 +1183,18 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
         if (s->lights[i].spectrum >= s->n_spectra) return fail(c, IRIS_E_ARG, "light spectrum out of range");
         if (s->lights[i].prim >= s->n_prims) return fail(c, IRIS_E_ARG, "light prim out of range");
     }
+    const iris_envmap_desc *em = s->env_map;
+    if (em && em->width != 0) {
+        if (!em->texels || em->height == 0) return fail(c, IRIS_E_ARG, "env_map without texels or height");
+        if ((uint64_t)em->width * em->height > (1ull << 28)) return fail(c, IRIS_E_LIMIT, "env_map above 2^28 texels");
+    } else {
+        em = nullptr;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
+    dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
+    c->d_env_texels = c->d_env_func = c->d_env_cond = c->d_env_marg = nullptr;
     c->d_spheres = c->d_prim_info = c->d_bsdfs = c->d_spectra = c->d_lights = nullptr;
     c->d_bvh_nodes = c->d_bvh_spheres = c->d_bvh_prim = nullptr;
     c->sc = SceneDev{};
@@ -1192,12 +1235,30 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
             c->bvh_depth = bvh.depth;
         }
     }
+    // environment map: texels and the sampling tables (built on the host, iris_envmap_tables) go to HBM
+    if (em) {
+        const size_t n = (size_t)em->width * em->height;
+        std::vector<float> func(n), cond((size_t)(em->width + 1) * em->height), marg(em->height + 1);
+        float integral = 0.0f;
+        if (iris_envmap_tables(em, func.data(), cond.data(), marg.data(), &integral) != IRIS_OK) return fail(c, IRIS_E_ARG, "env_map tables");
+        HIP_TRY(c, up(&c->d_env_texels, em->texels, sizeof(float) * 4 * n));
+        HIP_TRY(c, up(&c->d_env_func, func.data(), sizeof(float) * func.size()));
+        HIP_TRY(c, up(&c->d_env_cond, cond.data(), sizeof(float) * cond.size()));
+        HIP_TRY(c, up(&c->d_env_marg, marg.data(), sizeof(float) * marg.size()));
+        c->sc.env_texels = (const float4 *)c->d_env_texels;
+        c->sc.env_func = (const float *)c->d_env_func;
+        c->sc.env_cond_cdf = (const float *)c->d_env_cond;
+        c->sc.env_marg_cdf = (const float *)c->d_env_marg;
+        c->sc.env_w = em->width;
+        c->sc.env_h = em->height;
+        c->sc.env_integral = integral;
+    }
     // scene class: only Lambertian BSDFs and only constant spectra -> the specialised kernels apply
-    bool lc = true;
+    bool lc = em == nullptr;
     for (uint32_t i = 0; i < s->n_bsdfs; i++) lc = lc && s->bsdfs[i].kind == IRIS_BSDF_LAMBERTIAN;
     for (uint32_t i = 0; i < s->n_spectra; i++) lc = lc && s->spectra[i].kind == IRIS_SPEC_CONSTANT;
     c->scene_is_lambert_constant = lc;
-    c->scene_class = (c->specialize && lc) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL;
+    c->scene_class = em ? IRIS_CLS_GENERAL_ENV : ((c->specialize && lc) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL);
     c->have_scene = true;
     return IRIS_OK;
 }

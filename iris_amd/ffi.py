@@ -19,7 +19,8 @@ EXPORTS = (
     "iris_ctx_create", "iris_ctx_destroy", "iris_last_error", "iris_ctx_set_option", "iris_scene_upload",
     "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_film_to_rgb",
     "iris_get_stats", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
-    "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
+    "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_envmap_tables", "iris_oct_to_dir", "iris_dir_to_oct",
+    "iris_envmap_from_latlong", "iris_envmap_texels_from_rgb", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
 )
 
 
@@ -43,11 +44,15 @@ class Light(C.Structure):
     _fields_ = [("spectrum", C.c_uint32), ("prim", C.c_uint32)]
 
 
+class EnvmapDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("texels", C.POINTER(C.c_float)), ("importance", C.POINTER(C.c_float))]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("n_prims", C.c_uint32), ("spheres", C.POINTER(Sphere)), ("prim_material", C.POINTER(C.c_int32)),
                 ("prim_light", C.POINTER(C.c_int32)), ("n_bsdfs", C.c_uint32), ("bsdfs", C.POINTER(Bsdf)),
                 ("n_spectra", C.c_uint32), ("spectra", C.POINTER(Spectrum)), ("n_lights", C.c_uint32),
-                ("lights", C.POINTER(Light))]
+                ("lights", C.POINTER(Light)), ("env_map", C.POINTER(EnvmapDesc))]
 
 
 class Camera(C.Structure):
@@ -106,6 +111,11 @@ def load():
         "iris_upsample_table_resolution": (C.c_uint32, [vp]),
         "iris_upsample_get_spectrum": (C.c_int, [vp, fp, C.POINTER(Spectrum)]),
         "iris_upsample_get_spectrum_hdr": (C.c_int, [vp, fp, C.POINTER(Spectrum)]),
+        "iris_envmap_tables": (C.c_int, [C.POINTER(EnvmapDesc), fp, fp, fp, fp]),
+        "iris_oct_to_dir": (None, [C.c_float, C.c_float, fp]),
+        "iris_dir_to_oct": (None, [fp, fp]),
+        "iris_envmap_from_latlong": (C.c_int, [fp, u32, u32, u32, u32, fp]),
+        "iris_envmap_texels_from_rgb": (C.c_int, [vp, fp, C.c_size_t, C.c_float, fp, fp]),
         "iris_dbg_sampler": (C.c_int, [vp, u32, u32p, u32, u32, fp]),
         "iris_dbg_raygen": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(RenderParams), u32, u32p, fp, fp, fp]),
         "iris_dbg_intersect": (C.c_int, [vp, u32, fp, fp, i32p, fp]),

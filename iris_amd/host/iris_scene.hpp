@@ -147,6 +147,7 @@ class Scene {
             d.spectra = spectra.data();
             d.n_lights = (uint32_t)lights.size();
             d.lights = lights.data();
+            d.env_map = nullptr;  // Scene._env_map (scene.rs:27): the reference never fills it
             return d;
         }
     };

@@ -98,6 +98,106 @@ class UpsampleTable:
     __del__ = close
 
 
+class EnvMap:
+    """Scene._env_map: Vec<UpsampledHdrSpectrum> (scene.rs:27).  The reference declares it and never fills it;
+    layout and sampling are this build's (docs/SPEC.md section 6): (height, width, 4) f32 texels
+    (c0, c1, c2, hdr_coefficient) in the octahedral layout, plus per-texel importance for the sampling CDFs."""
+
+    def __init__(self, texels, importance=None):
+        self.texels = np.ascontiguousarray(texels, np.float32)
+        assert self.texels.ndim == 3 and self.texels.shape[2] == 4
+        self.height, self.width = self.texels.shape[:2]
+        self.importance = None if importance is None else np.ascontiguousarray(importance, np.float32).reshape(self.height, self.width)
+
+    @classmethod
+    def constant(cls, value, width=8, height=8):
+        """Uniform white environment of spectral radiance `value`: zero sigmoid coefficients evaluate to 0.5
+        (upsample.rs:35-41), so hdr_coefficient = 2 * value."""
+        t = np.zeros((height, width, 4), np.float32)
+        t[..., 3] = 2.0 * value
+        return cls(t)
+
+    @classmethod
+    def from_rgb(cls, rgb_oct, table, max_hdr=float("inf")):
+        """Octahedral (H, W, 3) linear-sRGB image -> texels through UpsampleTable::get_spectrum_hdr
+        (upsample.rs:46-56; its clamp at 50 is the reference's stop-gap for maps that are NOT importance
+        sampled, so the default here is no clamp); importance = luminance."""
+        rgb = np.ascontiguousarray(rgb_oct, np.float32)
+        h, w = rgb.shape[:2]
+        texels = np.zeros((h, w, 4), np.float32)
+        imp = np.zeros((h, w), np.float32)
+        fp = C.POINTER(C.c_float)
+        rc = ffi.load().iris_envmap_texels_from_rgb(table.handle, rgb.ctypes.data_as(fp), h * w, C.c_float(max_hdr),
+                                                    texels.ctypes.data_as(fp), imp.ctypes.data_as(fp))
+        if rc != ffi.IRIS_OK:
+            raise ffi.IrisError("iris_envmap_texels_from_rgb failed (%d)" % rc)
+        return cls(texels, imp)
+
+    @staticmethod
+    def latlong_to_oct(rgb_latlong, out_width, out_height):
+        src = np.ascontiguousarray(rgb_latlong, np.float32)
+        out = np.zeros((out_height, out_width, 3), np.float32)
+        fp = C.POINTER(C.c_float)
+        rc = ffi.load().iris_envmap_from_latlong(src.ctypes.data_as(fp), src.shape[1], src.shape[0], out_width, out_height, out.ctypes.data_as(fp))
+        if rc != ffi.IRIS_OK:
+            raise ffi.IrisError("iris_envmap_from_latlong failed (%d)" % rc)
+        return out
+
+    @staticmethod
+    def texel_directions(width, height):
+        """(H, W, 3) unit directions of the texel centres (iris_oct_to_dir)."""
+        L = ffi.load()
+        out = np.zeros((height, width, 3), np.float32)
+        d = (C.c_float * 3)()
+        for r in range(height):
+            for c in range(width):
+                L.iris_oct_to_dir(C.c_float(np.float32((c + 0.5) / width * 2 - 1)), C.c_float(np.float32((r + 0.5) / height * 2 - 1)), d)
+                out[r, c] = d[:]
+        return out
+
+    @classmethod
+    def sky(cls, table, width=256, height=256, sun_scale=400.0):
+        """Procedural HDR sky (no .hdr file ships with the reference, .gitignore:7): blue-to-white gradient over a
+        dark ground, and a small sun four hundred times brighter than the sky -- the case CDF sampling is for."""
+        u = (np.arange(width, dtype=np.float64) + 0.5) / width * 2 - 1
+        v = (np.arange(height, dtype=np.float64) + 0.5) / height * 2 - 1
+        uu, vv = np.meshgrid(u, v)
+        y = 1 - np.abs(uu) - np.abs(vv)
+        x = np.where(y >= 0, uu, (1 - np.abs(vv)) * np.where(uu >= 0, 1.0, -1.0))
+        z = np.where(y >= 0, vv, (1 - np.abs(uu)) * np.where(vv >= 0, 1.0, -1.0))
+        n = np.sqrt(x * x + y * y + z * z)
+        x, y, z = x / n, y / n, z / n
+        up = np.clip(y, 0.0, 1.0)[..., None]
+        zenith, horizon, ground = np.array([0.25, 0.45, 1.0]), np.array([0.9, 0.9, 0.85]), np.array([0.08, 0.07, 0.06])
+        rgb = np.where(y[..., None] >= 0, horizon + (zenith - horizon) * np.sqrt(up), ground)
+        sun = np.array([0.45, 0.65, -0.6])
+        sun = sun / np.linalg.norm(sun)
+        cos_s = x * sun[0] + y * sun[1] + z * sun[2]
+        disc = np.clip((cos_s - np.cos(np.radians(4.0))) / (np.cos(np.radians(2.0)) - np.cos(np.radians(4.0))), 0.0, 1.0)
+        rgb = rgb + disc[..., None] * sun_scale * np.array([1.0, 0.9, 0.7])
+        return cls.from_rgb(rgb.astype(np.float32), table)
+
+    def desc(self):
+        """-> (iris_envmap_desc, keepalive)"""
+        fp = C.POINTER(C.c_float)
+        d = ffi.EnvmapDesc(self.width, self.height, self.texels.ctypes.data_as(fp),
+                           self.importance.ctypes.data_as(fp) if self.importance is not None else None)
+        return d, (self.texels, self.importance)
+
+    def tables(self):
+        """The sampling tables iris_scene_upload builds: func (H, W), cond_cdf (H, W+1), marg_cdf (H+1,), integral."""
+        d, keep = self.desc()
+        func = np.zeros((self.height, self.width), np.float32)
+        cond = np.zeros((self.height, self.width + 1), np.float32)
+        marg = np.zeros(self.height + 1, np.float32)
+        integral = C.c_float()
+        fp = C.POINTER(C.c_float)
+        rc = ffi.load().iris_envmap_tables(C.byref(d), func.ctypes.data_as(fp), cond.ctypes.data_as(fp), marg.ctypes.data_as(fp), C.byref(integral))
+        if rc != ffi.IRIS_OK:
+            raise ffi.IrisError("iris_envmap_tables failed (%d)" % rc)
+        return func, cond, marg, np.float32(integral.value)
+
+
 # ---- shape/ ----------------------------------------------------------------
 @dataclass
 class Sphere:  # shape/sphere.rs:7-16
@@ -163,6 +263,7 @@ class FlatScene:
     bsdfs: List[tuple]         # (kind, spec_a, spec_b, p0, p1)
     spectra: List[tuple]       # (kind, c0, c1, c2, hdr)
     lights: List[tuple]        # (spectrum, prim)
+    env_map: Optional[EnvMap] = None
 
     def to_desc(self):
         """Returns (iris_scene_desc, keepalive) for the C ABI."""
@@ -173,8 +274,12 @@ class FlatScene:
         bs = (ffi.Bsdf * max(1, len(self.bsdfs)))(*[ffi.Bsdf(*b) for b in self.bsdfs])
         sp = (ffi.Spectrum * max(1, len(self.spectra)))(*[ffi.Spectrum(*s) for s in self.spectra])
         li = (ffi.Light * max(1, len(self.lights)))(*[ffi.Light(*l) for l in self.lights])
-        desc = ffi.SceneDesc(n, spheres, pm, pl, len(self.bsdfs), bs, len(self.spectra), sp, len(self.lights), li)
-        return desc, (spheres, pm, pl, bs, sp, li)
+        env_ptr, env_keep = None, None
+        if self.env_map is not None:
+            ed, ek = self.env_map.desc()
+            env_ptr, env_keep = C.pointer(ed), (ed, ek)
+        desc = ffi.SceneDesc(n, spheres, pm, pl, len(self.bsdfs), bs, len(self.spectra), sp, len(self.lights), li, env_ptr)
+        return desc, (spheres, pm, pl, bs, sp, li, env_keep)
 
 
 @dataclass
@@ -183,6 +288,7 @@ class Scene:
     lights: List[tuple] = field(default_factory=list)     # PrimIndex<Spectrum>: (spectrum, prim_index)
     materials: List[object] = field(default_factory=list)  # PrimIndex<Bsdf>.data
     primitives: List[tuple] = field(default_factory=list)  # (Sphere, material_index|None, light_index|None)
+    env_map: Optional[EnvMap] = None                        # scene.rs:27 (`_env_map`)
 
     def add_light(self, geom: Sphere, light):  # scene.rs:71-78
         self.lights.append((light, len(self.primitives)))
@@ -249,6 +355,24 @@ class Scene:
         return scene
 
     @classmethod
+    def glossy_dielectric_env(cls, table, env_size=256):
+        """BASELINE config E as named: the glossy/dielectric scene lit by an HDR environment map (procedural sky
+        with a sun) in addition to the sphere light."""
+        scene = cls.glossy_dielectric()
+        scene.env_map = EnvMap.sky(table, env_size, env_size)
+        return scene
+
+    @classmethod
+    def env_furnace(cls, albedo=0.5, emission=1.0):
+        """White-furnace check of the environment map: one Lambertian sphere of albedo rho in a uniform
+        environment of radiance L.  A convex body sees only the environment, so it reflects exactly rho*L in
+        every direction: pixels on the sphere converge to rho*L, the others to L (rho = 1: the sphere vanishes)."""
+        scene = cls()
+        scene.add_material(Sphere((0.0, 0.0, 3.0), 1.0), LambertianBsdf(ConstantSpectrum(albedo)))
+        scene.env_map = EnvMap.constant(emission)
+        return scene
+
+    @classmethod
     def coloured(cls, table):
         """S1's geometry with RGB materials and an HDR RGB light, all through the upsampling table
         (UpsampleTable::get_spectrum / get_spectrum_hdr, upsample.rs:46-106): exercises the sigmoid spectra."""
@@ -278,7 +402,7 @@ class Scene:
             spheres[i] = (g.position[0], g.position[1], g.position[2], g.radius)
             pm[i] = -1 if m is None else m
             pl[i] = -1 if l is None else l
-        return FlatScene(spheres, pm, pl, bsdfs, spectra, lights)
+        return FlatScene(spheres, pm, pl, bsdfs, spectra, lights, self.env_map)
 
 
 class _Pcg32:

@@ -866,6 +866,14 @@ struct orc_scene {
     bsdf_t *bsdfs; uint32_t n_bsdfs;          /* scene.materials (PrimIndex data) */
     int *light_spectrum; int *light_prim; uint32_t n_lights; /* scene.lights (PrimIndex{data, prim_index}) */
     primitive_t *prims; uint32_t n_prims;
+    /* Scene._env_map: Vec<UpsampledHdrSpectrum> (scene.rs:27), never filled by the reference.  Layout and
+     * sampling tables are this build's definition (docs/SPEC.md section 6). */
+    uint32_t env_w, env_h;
+    float *env_texels;   /* 4 per texel: c0, c1, c2, hdr_coefficient */
+    float *env_func;     /* importance * texel solid-angle weight */
+    float *env_cond_cdf; /* (env_w + 1) per row */
+    float *env_marg_cdf; /* env_h + 1 */
+    float env_integral;
 };
 
 /* lambertian.rs:24-31 */
@@ -995,7 +1003,8 @@ static void bsdf_sample(const orc_scene *sc, const bsdf_t *b, v3 wo, f4 wl, samp
 orc_scene *orc_scene_new(void) { return (orc_scene *)calloc(1, sizeof(orc_scene)); }
 void orc_scene_free(orc_scene *s) {
     if (!s) return;
-    free(s->spectra); free(s->bsdfs); free(s->light_spectrum); free(s->light_prim); free(s->prims); free(s);
+    free(s->spectra); free(s->bsdfs); free(s->light_spectrum); free(s->light_prim); free(s->prims);
+    free(s->env_texels); free(s->env_func); free(s->env_cond_cdf); free(s->env_marg_cdf); free(s);
 }
 uint32_t orc_scene_num_prims(const orc_scene *s) { return s->n_prims; }
 int orc_scene_add_spectrum(orc_scene *s, uint32_t kind, float c0, float c1, float c2, float hdr) {
@@ -1086,14 +1095,6 @@ static int scene_ray_hits_object(const orc_scene *s, const ray_t *ray, int light
     }
     return closest_hit_is_obj;
 }
-/* scene.rs:168-172 */
-static void scene_pick_one_light(const orc_scene *s, sampler_t *sampler, int *spectrum, int *prim, float *weight) {
-    uint64_t light_idx = sampler_gen_array_index(sampler, s->n_lights);
-    *spectrum = s->light_spectrum[light_idx];
-    *prim = s->light_prim[light_idx];
-    *weight = (float)s->n_lights;
-}
-
 int orc_scene_intersect(const orc_scene *s, const float o[3], const float d[3], float *t_out,
                         float point[3], float normal[3], float tangent[3], float bitangent[3], int *back_face) {
     ray_t ray = {v3_new(o[0], o[1], o[2]), v3_new(d[0], d[1], d[2])};
@@ -1112,20 +1113,185 @@ int orc_scene_intersect(const orc_scene *s, const float o[3], const float d[3], 
     return prim;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* environment map (docs/SPEC.md section 6).  The reference only stubs it:  */
+/* Scene._env_map (scene.rs:27), background_emission returning 0            */
+/* (scene.rs:112-114), get_spectrum_hdr's clamp "until we importance sample */
+/* the env map" (upsample.rs:46-56).  No reference behaviour to match: the  */
+/* definition is this build's, the oracle restates it for the GPU parity.   */
+/* ------------------------------------------------------------------------ */
+
+static inline float env_sgn(float a) { return a >= 0.0f ? 1.0f : -1.0f; }
+/* octahedral square [-1,1]^2 -> point on the octahedron |x|+|y|+|z| = 1, y is the pole axis */
+static v3 oct_point(float u, float v) {
+    float y = (1.0f - fabsf(u)) - fabsf(v);
+    if (y >= 0.0f) return v3_new(u, y, v);
+    return v3_new((1.0f - fabsf(v)) * env_sgn(u), y, (1.0f - fabsf(u)) * env_sgn(v));
+}
+/* direction -> (u, v) and |q|^3, the Jacobian of d(omega) = du dv / |q|^3 */
+static void dir_to_uv(v3 d, float *u, float *v, float *jac) {
+    float s = (fabsf(d.x) + fabsf(d.y)) + fabsf(d.z);
+    v3 q = v3_new(d.x / s, d.y / s, d.z / s);
+    if (q.y >= 0.0f) { *u = q.x; *v = q.z; }
+    else { *u = (1.0f - fabsf(q.z)) * env_sgn(q.x); *v = (1.0f - fabsf(q.x)) * env_sgn(q.z); }
+    float l2 = v3_len_squared(q);
+    *jac = l2 * sqrtf(l2);
+}
+static inline uint32_t env_texel_coord(float t, uint32_t n) {
+    uint64_t i = f_as_usize((t * 0.5f + 0.5f) * (float)n);
+    return i < n ? (uint32_t)i : n - 1u;
+}
+/* emission towards -d and the solid-angle density with which env_sample produces d */
+static void env_eval(const orc_scene *sc, v3 d, f4 wl, f4 *le, float *pdf) {
+    float u, v, jac;
+    dir_to_uv(d, &u, &v, &jac);
+    uint32_t c = env_texel_coord(u, sc->env_w), r = env_texel_coord(v, sc->env_h);
+    size_t idx = (size_t)r * sc->env_w + c;
+    const float *t = &sc->env_texels[4 * idx];
+    spectrum_t sp = {ORC_SPEC_UPSAMPLED_HDR, t[0], t[1], t[2], t[3]};
+    *le = spectrum_evaluate(&sp, wl);
+    *pdf = sc->env_integral > 0.0f ? ((sc->env_func[idx] / sc->env_integral) * 0.25f) * jac : 0.0f;
+}
+/* piecewise-constant 1-D distribution: largest idx with cdf[idx] <= u, continuous position in [0, 1] */
+static float env_sample_1d(const float *cdf, uint32_t n, float u, uint32_t *idx) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid; else hi = mid;
+    }
+    float den = cdf[lo + 1] - cdf[lo];
+    float du = u - cdf[lo];
+    if (den > 0.0f) du = du / den;
+    *idx = lo;
+    return ((float)lo + du) / (float)n;
+}
+static v3 env_sample(const orc_scene *sc, float u0, float u1) {
+    uint32_t r, c;
+    float vv = env_sample_1d(sc->env_marg_cdf, sc->env_h, u0, &r);
+    float uu = env_sample_1d(sc->env_cond_cdf + (size_t)r * (sc->env_w + 1u), sc->env_w, u1, &c);
+    return v3_normalize(oct_point(2.0f * uu - 1.0f, 2.0f * vv - 1.0f));
+}
+/* cdf[0..n] of n non-negative values, accumulated in binary64; returns their mean */
+static double env_build_cdf(const float *func, uint32_t n, float *cdf) {
+    double acc = 0.0;
+    for (uint32_t i = 0; i < n; i++) acc += (double)func[i];
+    double run = 0.0;
+    cdf[0] = 0.0f;
+    for (uint32_t i = 1; i <= n; i++) {
+        run += (double)func[i - 1];
+        cdf[i] = acc > 0.0 ? (float)(run / acc) : (float)i / (float)n;
+    }
+    cdf[n] = 1.0f;
+    return acc / (double)n;
+}
+int orc_scene_set_envmap(orc_scene *s, uint32_t w, uint32_t h, const float *texels, const float *importance) {
+    free(s->env_texels); free(s->env_func); free(s->env_cond_cdf); free(s->env_marg_cdf);
+    s->env_texels = s->env_func = s->env_cond_cdf = s->env_marg_cdf = NULL;
+    s->env_w = s->env_h = 0;
+    s->env_integral = 0.0f;
+    if (w == 0 || h == 0 || !texels) return 0;
+    size_t n = (size_t)w * h;
+    s->env_texels = (float *)malloc(n * 4 * sizeof(float));
+    s->env_func = (float *)malloc(n * sizeof(float));
+    s->env_cond_cdf = (float *)malloc((size_t)(w + 1) * h * sizeof(float));
+    s->env_marg_cdf = (float *)malloc((size_t)(h + 1) * sizeof(float));
+    float *row_mean = (float *)malloc(h * sizeof(float));
+    memcpy(s->env_texels, texels, n * 4 * sizeof(float));
+    for (uint32_t r = 0; r < h; r++) {
+        for (uint32_t c = 0; c < w; c++) {
+            float u = (((float)c + 0.5f) / (float)w) * 2.0f - 1.0f;
+            float v = (((float)r + 0.5f) / (float)h) * 2.0f - 1.0f;
+            v3 q = oct_point(u, v);
+            float l2 = v3_len_squared(q);
+            float imp = importance ? importance[(size_t)r * w + c] : texels[4 * ((size_t)r * w + c) + 3];
+            if (!(imp > 0.0f)) imp = 0.0f; /* negative or NaN importance: never sampled */
+            s->env_func[(size_t)r * w + c] = imp / (l2 * sqrtf(l2));
+        }
+        row_mean[r] = (float)env_build_cdf(s->env_func + (size_t)r * w, w, s->env_cond_cdf + (size_t)r * (w + 1));
+    }
+    s->env_integral = (float)env_build_cdf(row_mean, h, s->env_marg_cdf);
+    free(row_mean);
+    s->env_w = w;
+    s->env_h = h;
+    return 1;
+}
+void orc_envmap_tables(const orc_scene *s, const float **func, const float **cond_cdf, const float **marg_cdf, float *integral) {
+    *func = s->env_func; *cond_cdf = s->env_cond_cdf; *marg_cdf = s->env_marg_cdf; *integral = s->env_integral;
+}
+void orc_oct_point(float u, float v, float out[3]) { v3 q = oct_point(u, v); out[0] = q.x; out[1] = q.y; out[2] = q.z; }
+void orc_dir_to_uv(const float d[3], float uv[2], float *jac) { dir_to_uv(v3_new(d[0], d[1], d[2]), &uv[0], &uv[1], jac); }
+void orc_env_eval(const orc_scene *s, const float d[3], const float wl[4], float le[4], float *pdf) {
+    f4 l;
+    env_eval(s, v3_new(d[0], d[1], d[2]), f4_new(wl[0], wl[1], wl[2], wl[3]), &l, pdf);
+    memcpy(le, l.v, sizeof l.v);
+}
+void orc_env_sample(const orc_scene *s, float u0, float u1, float d[3]) { v3 r = env_sample(s, u0, u1); d[0] = r.x; d[1] = r.y; d[2] = r.z; }
+
 /* ------------------------------------------------------------------------ */
 /* integrator/                                                                */
 /* ------------------------------------------------------------------------ */
 
 typedef struct { orc_trace *trace; uint32_t max_depth, min_depth; } int_ctx;
 
-/* hwss_naive.rs:95-157 (hwss != 0) and swss_naive.rs:92-153 (hwss == 0) */
+/* hwss_naive.rs:95-157 (hwss != 0) and swss_naive.rs:92-153 (hwss == 0).
+ * With an environment map (docs/SPEC.md section 6) the map is one more entry of the light list: index
+ * n_lights of pick_one_light.  Its two strategies mirror the sphere light's: a direction drawn from the map's
+ * CDFs (2 draws, as Sphere::sample) that must reach nothing, and the BSDF-sampled ray counted when it leaves
+ * the scene; emission and density of both come from env_eval on the ray's direction. */
 static f4 direct_light(const orc_scene *sc, int hwss, const bsdf_t *bsdf, const isect_t *hit, const ray_t *ray,
                        f4 wl, sampler_t *sampler) {
     f4 radiance = f4_splat(0.0f);
     v3 shading_wo = world_to_shading(hit, v3_neg(ray->d));
-    int light_spec, light_prim;
-    float light_pick_weight;
-    scene_pick_one_light(sc, sampler, &light_spec, &light_prim, &light_pick_weight);
+    const uint32_t n_total = sc->n_lights + (sc->env_w ? 1u : 0u);
+    uint64_t light_idx = sampler_gen_array_index(sampler, n_total); /* scene.rs:168-172 */
+    float light_pick_weight = (float)n_total;
+    if (light_idx >= sc->n_lights) { /* the environment map */
+        {
+            float u0 = sampler_gen_0_1(sampler);
+            float u1 = sampler_gen_0_1(sampler);
+            v3 dir = env_sample(sc, u0, u1);
+            ray_t ray_to_light = ray_spawn(hit->point, dir, hit->normal);
+            f4 light_emission;
+            float light_pdf;
+            env_eval(sc, ray_to_light.d, wl, &light_emission, &light_pdf);
+            int facing_forward = v3_dot(dir, hit->normal) > 0.0f;
+            if (light_pdf > 0.0f && facing_forward != hit->back_face) {
+                isect_t h2;
+                float t2;
+                if (scene_intersection(sc, &ray_to_light, &h2, &t2) < 0) {
+                    v3 shading_wi = world_to_shading(hit, ray_to_light.d);
+                    f4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl);
+                    f4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
+                    float cos_theta = fabsf(sh_cos_theta(shading_wi));
+                    float mis_weight = hwss ? balance_heuristic_2(f4_splat(light_pdf), bsdf_pdfs)
+                                            : light_pdf / (f4_hero(bsdf_pdfs) + light_pdf);
+                    radiance = f4_add(radiance, f4_divs(f4_muls(f4_mul(f4_smul(mis_weight, light_emission), bsdf_values), cos_theta), light_pdf));
+                }
+            }
+        }
+        {
+            v3 wi;
+            f4 bsdf_values, bsdf_pdfs;
+            bsdf_sample(sc, bsdf, shading_wo, wl, sampler, &wi, &bsdf_values, &bsdf_pdfs);
+            float cos_theta = fabsf(sh_cos_theta(wi));
+            ray_t ray_to_light = ray_spawn(hit->point, shading_to_world(hit, wi), hit->normal);
+            if (f4_hero(bsdf_pdfs) > 0.0f) {
+                isect_t h2;
+                float t2;
+                if (scene_intersection(sc, &ray_to_light, &h2, &t2) < 0) {
+                    f4 light_emission;
+                    float light_pdf;
+                    env_eval(sc, ray_to_light.d, wl, &light_emission, &light_pdf);
+                    float mis_weight = hwss ? balance_heuristic_2(bsdf_pdfs, f4_splat(light_pdf))
+                                            : f4_hero(bsdf_pdfs) / (f4_hero(bsdf_pdfs) + light_pdf);
+                    radiance = f4_add(radiance, f4_divs(f4_muls(f4_mul(f4_smul(mis_weight, light_emission), bsdf_values), cos_theta), f4_hero(bsdf_pdfs)));
+                }
+            }
+        }
+        return f4_muls(radiance, light_pick_weight);
+    }
+    int light_spec = sc->light_spectrum[light_idx], light_prim = sc->light_prim[light_idx];
     f4 light_emission = spectrum_evaluate(&sc->spectra[light_spec], wl);
     const sphere_t *light_geom = &sc->prims[light_prim].geometry;
 
@@ -1175,7 +1341,19 @@ static f4 integrator_radiance(const orc_scene *sc, uint32_t integrator, const in
         isect_t hit;
         float t;
         int prim_idx = scene_intersection(sc, &ray, &hit, &t);
-        if (prim_idx < 0) break;
+        if (prim_idx < 0) {
+            /* `None => break` (hwss_naive.rs:41-44).  With an environment map (docs/SPEC.md section 6, after the
+             * commented miss branch of scene.rs:351-353) the map's emission is added under the rule the
+             * integrator has for emitters it hits: at bounce 0 only with next-event estimation, always without. */
+            if (sc->env_w && (!naive || bounces == 0)) {
+                f4 le;
+                float pdf_unused;
+                env_eval(sc, ray.d, wl, &le, &pdf_unused);
+                if (hwss) radiance = f4_add(radiance, f4_muls(f4_mul(throughput, le), balance_heuristic_1(path_pdfs)));
+                else radiance = f4_add(radiance, f4_mul(throughput, le));
+            }
+            break;
+        }
         const primitive_t *prim = &sc->prims[prim_idx];
         if (ic->trace && ic->trace->n_hits < ORC_TRACE_MAX_DEPTH) {
             ic->trace->hit_prim[ic->trace->n_hits] = prim_idx;

@@ -136,6 +136,15 @@ int orc_scene_add_bsdf(orc_scene *s, uint32_t kind, int spec_a, int spec_b, floa
 int orc_scene_add_sphere(orc_scene *s, float cx, float cy, float cz, float r, int material, int light_spectrum);
 void orc_scene_dummy(orc_scene *s); /* Scene::dummy, scene.rs:31-69 */
 uint32_t orc_scene_num_prims(const orc_scene *s);
+/* Environment map (docs/SPEC.md section 6; the reference only stubs it: scene.rs:27, :112-114): w*h texels
+ * of (c0, c1, c2, hdr_coefficient) in the octahedral layout, importance (may be NULL: the hdr coefficient)
+ * per texel.  w == 0 removes the map. */
+int orc_scene_set_envmap(orc_scene *s, uint32_t w, uint32_t h, const float *texels, const float *importance);
+void orc_envmap_tables(const orc_scene *s, const float **func, const float **cond_cdf, const float **marg_cdf, float *integral);
+void orc_oct_point(float u, float v, float out[3]);
+void orc_dir_to_uv(const float d[3], float uv[2], float *jac);
+void orc_env_eval(const orc_scene *s, const float d[3], const float wl[4], float le[4], float *pdf);
+void orc_env_sample(const orc_scene *s, float u0, float u1, float d[3]);
 
 /* shape/sphere.rs + scene.rs scans, on explicit rays */
 int orc_scene_intersect(const orc_scene *s, const float o[3], const float d[3], float *t_out,

@@ -96,6 +96,12 @@ def lib():
         "orc_scene_add_sphere": (C.c_int, [C.c_void_p] + [C.c_float] * 4 + [C.c_int, C.c_int]),
         "orc_scene_dummy": (None, [C.c_void_p]),
         "orc_scene_num_prims": (u32, [C.c_void_p]),
+        "orc_scene_set_envmap": (C.c_int, [C.c_void_p, u32, u32, fp, fp]),
+        "orc_envmap_tables": (None, [C.c_void_p, C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), fp]),
+        "orc_oct_point": (None, [C.c_float, C.c_float, fp]),
+        "orc_dir_to_uv": (None, [fp, fp, fp]),
+        "orc_env_eval": (None, [C.c_void_p, fp, fp, fp, fp]),
+        "orc_env_sample": (None, [C.c_void_p, C.c_float, C.c_float, fp]),
         "orc_scene_intersect": (C.c_int, [C.c_void_p, fp, fp, fp, fp, fp, fp, fp, C.POINTER(C.c_int)]),
         "orc_trace_sample": (None, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), u32, u32, u32, C.POINTER(Trace)]),
         "orc_pixel_xyz": (None, [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), u32, u32, fp]),
@@ -153,6 +159,29 @@ class OracleScene:
             # prim_light[i] >= 0 <=> the primitive has a light; the oracle's add_sphere appends the light
             L.orc_scene_add_sphere(self.h, cx, cy, cz, r, int(flat.prim_material[i]),
                                    int(light_spec[i]) if flat.prim_light[i] >= 0 else -1)
+        env = getattr(flat, "env_map", None)
+        if env is not None:
+            L.orc_scene_set_envmap(self.h, env.width, env.height, _fp(env.texels),
+                                   _fp(env.importance) if env.importance is not None else None)
+
+    def env_tables(self, width, height):
+        fp = C.POINTER(C.c_float)
+        f, c, m, integral = fp(), fp(), fp(), C.c_float()
+        lib().orc_envmap_tables(self.h, C.byref(f), C.byref(c), C.byref(m), C.byref(integral))
+        return (np.ctypeslib.as_array(f, (height, width)).copy(), np.ctypeslib.as_array(c, (height, width + 1)).copy(),
+                np.ctypeslib.as_array(m, (height + 1,)).copy(), np.float32(integral.value))
+
+    def env_eval(self, d, wl):
+        d, wl = f32a(d), f32a(wl)
+        le = np.zeros(4, np.float32)
+        pdf = C.c_float()
+        lib().orc_env_eval(self.h, _fp(d), _fp(wl), _fp(le), C.byref(pdf))
+        return le, np.float32(pdf.value)
+
+    def env_sample(self, u0, u1):
+        d = np.zeros(3, np.float32)
+        lib().orc_env_sample(self.h, C.c_float(u0), C.c_float(u1), _fp(d))
+        return d
 
     @classmethod
     def dummy(cls):
