@@ -62,7 +62,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU")
-    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3"])
+    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3", "s1env", "s3env"],
+                    help="s1 default scene, s2 10k spheres, s3 glossy/dielectric; ...env: the same under the HDR sky (config E = s3env)")
+    ap.add_argument("--env-size", type=int, default=1024, help="environment map is env_size x env_size texels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--multi-kernel", action="store_true", help="launch the two stages as separate kernels")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="iris_ctx_set_option tuning knob (repeatable)")
@@ -82,8 +84,11 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[args.scene]()
-    max_depth = 32 if args.scene == "s3" else iris_amd.scene.MAX_DEPTH
+    scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[args.scene[:2]]()
+    if args.scene.endswith("env"):  # procedural HDR sky through the RGB -> spectrum table (a data fixture; tools/rgb2spec_opt.c makes it)
+        table = iris_amd.UpsampleTable(os.path.join(ROOT, "tests", "golden", "srgb_res16.coeff"))
+        scene.env_map = iris_amd.EnvMap.sky(table, args.env_size, args.env_size)
+    max_depth = 32 if args.scene.startswith("s3") else iris_amd.scene.MAX_DEPTH
     spp_total = args.spp * world
     render = iris_amd.Render(args.width, args.height, spp_total, scene, max_depth=max_depth)
     opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.opt}
@@ -133,7 +138,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config B per GPU: %s scene %dx%d, %d spp per GPU (%d spp total), HwssNaive, "
                                    "max_depth %d, spp-split + RCCL all-reduce of the XYZ film" %
-                                   ({"s1": "default (scene.rs:43-66, 3 spheres)", "s2": "10k-sphere (hierarchy unless --opt bvh_min_prims=0)", "s3": "glossy/dielectric"}[args.scene],
+                                   ({"s1": "default (scene.rs:43-66, 3 spheres)", "s2": "10k-sphere (hierarchy unless --opt bvh_min_prims=0)", "s3": "glossy/dielectric"}[args.scene[:2]]
+                                    + (" + %dx%d HDR environment map" % (args.env_size, args.env_size) if args.scene.endswith("env") else ""),
                                     args.width, args.height, args.spp, spp_total, max_depth),
                        "width": args.width, "height": args.height, "spp_per_gpu": args.spp, "parallelism": "spp-split x%d" % world},
             # rank 0's path-tracing kernel, timed with HIP events on its own stream inside the library

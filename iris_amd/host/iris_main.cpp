@@ -5,6 +5,7 @@
 //   iris_render [--width W] [--height H] [--spp N] [--scene dummy|furnace|spheres10k|glossy]
 //               [--integrator hwss_naive|hwss_slow|swss_naive|swss_slow] [--max-depth D] [--min-depth D]
 //               [--gpus G] [--device I] [--share-device] [--out out.exr|out.pfm] [--dump-scene]
+//               [--env none|white|sky] [--env-size N] [--table srgb.coeff]
 //
 // What it mirrors: WIDTH/HEIGHT/TOTAL_SPP and CurrentIntegrator (main.rs:27-31) become flags; the
 // thread pool popping tiles (main.rs:87-107) becomes one host thread per GPU, each rendering the
@@ -104,7 +105,8 @@ int usage(const char *argv0) {
     std::fprintf(stderr,
                  "usage: %s [--width W] [--height H] [--spp N] [--scene dummy|furnace|spheres10k|glossy]\n"
                  "          [--integrator hwss_naive|hwss_slow|swss_naive|swss_slow] [--max-depth D] [--min-depth D]\n"
-                 "          [--gpus G] [--device I] [--share-device] [--out FILE.exr|FILE.pfm] [--dump-scene]\n", argv0);
+                 "          [--gpus G] [--device I] [--share-device] [--out FILE.exr|FILE.pfm] [--dump-scene]\n"
+                 "          [--env none|white|sky] [--env-size N] [--table FILE.coeff]\n", argv0);
     return 2;
 }
 
@@ -116,7 +118,8 @@ int main(int argc, char **argv) {
     uint32_t integrator = IRIS_INT_HWSS_NAIVE;      // main.rs:31
     int gpus = 1, device = 0;
     bool dump_scene = false, share_device = false;
-    std::string scene_name = "dummy", out = "out.exr";
+    std::string scene_name = "dummy", out = "out.exr", env_name = "none", table_path = "data/srgb.coeff" /* upsample.rs:109 */;
+    uint32_t env_size = 256;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -129,6 +132,9 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = std::atoi(val());
         else if (a == "--scene") scene_name = val();
         else if (a == "--out") out = val();
+        else if (a == "--env") env_name = val();
+        else if (a == "--env-size") env_size = (uint32_t)std::strtoul(val(), nullptr, 10);
+        else if (a == "--table") table_path = val();
         else if (a == "--dump-scene") dump_scene = true;
         else if (a == "--share-device") share_device = true;  // all contexts on --device (rehearses --gpus on a 1-GPU box)
         else if (a == "--integrator") {
@@ -148,7 +154,18 @@ int main(int argc, char **argv) {
     else if (scene_name == "spheres10k") scene = iris_host::Scene::many_spheres();
     else if (scene_name == "glossy") scene = iris_host::Scene::glossy_dielectric();
     else return usage(argv[0]);
-    const iris_host::Scene::Flat flat = scene.flatten();
+    // Scene._env_map (scene.rs:27): none in the reference; here a uniform white map or the procedural HDR sky
+    if (env_name == "white") scene.env_map = iris_host::EnvMap::constant(1.0f);
+    else if (env_name == "sky") {
+        iris_upsample_table *table = nullptr;
+        if (env_size == 0 || iris_upsample_table_load(table_path.c_str(), &table) != IRIS_OK) {
+            std::fprintf(stderr, "--env sky needs an RGB->spectrum table: cannot load %s (tools/rgb2spec_opt.c makes one)\n", table_path.c_str());
+            return 1;
+        }
+        scene.env_map = iris_host::EnvMap::sky(table, env_size, env_size);
+        iris_upsample_table_free(table);
+    } else if (env_name != "none") return usage(argv[0]);
+    iris_host::Scene::Flat flat = scene.flatten();
 
     if (dump_scene) {  // the flat tables, one record per line (compared with the Python mirror in tests/)
         for (size_t i = 0; i < flat.spheres.size(); i++)

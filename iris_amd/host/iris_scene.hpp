@@ -62,6 +62,55 @@ struct Pcg32 {
     double uniform() { return (double)(next() >> 8) * (1.0 / 16777216.0); }
 };
 
+// Scene._env_map: Vec<UpsampledHdrSpectrum> (scene.rs:27; never filled by the reference).  Octahedral layout,
+// (c0, c1, c2, hdr_coefficient) per texel -- include/iris_hip.h, docs/SPEC.md section 6.
+struct EnvMap {
+    uint32_t width = 0, height = 0;
+    std::vector<float> texels, importance;
+    // uniform white environment of spectral radiance `value` (zero sigmoid coefficients evaluate to 0.5)
+    static EnvMap constant(float value, uint32_t w = 8, uint32_t h = 8) {
+        EnvMap e;
+        e.width = w; e.height = h;
+        e.texels.assign((size_t)w * h * 4, 0.0f);
+        for (size_t i = 0; i < (size_t)w * h; i++) e.texels[4 * i + 3] = 2.0f * value;
+        return e;
+    }
+    // octahedral RGB image -> texels through UpsampleTable::get_spectrum_hdr (upsample.rs:46-56), no clamp
+    static EnvMap from_rgb(const iris_upsample_table *table, const std::vector<float> &rgb, uint32_t w, uint32_t h) {
+        EnvMap e;
+        e.width = w; e.height = h;
+        e.texels.resize((size_t)w * h * 4);
+        e.importance.resize((size_t)w * h);
+        iris_envmap_texels_from_rgb(table, rgb.data(), (size_t)w * h, INFINITY, e.texels.data(), e.importance.data());
+        return e;
+    }
+    // the procedural HDR sky of iris_amd.EnvMap.sky: gradient over a dark ground and a sun 400x brighter
+    static EnvMap sky(const iris_upsample_table *table, uint32_t w = 256, uint32_t h = 256, double sun_scale = 400.0) {
+        std::vector<float> rgb((size_t)w * h * 3);
+        const double PI = 3.14159265358979323846;
+        double sun[3] = {0.45, 0.65, -0.6};
+        const double sl = std::sqrt(sun[0] * sun[0] + sun[1] * sun[1] + sun[2] * sun[2]);
+        for (double &c : sun) c /= sl;
+        const double c4 = std::cos(4.0 * PI / 180.0), c2 = std::cos(2.0 * PI / 180.0);
+        const double zenith[3] = {0.25, 0.45, 1.0}, horizon[3] = {0.9, 0.9, 0.85}, ground[3] = {0.08, 0.07, 0.06}, tint[3] = {1.0, 0.9, 0.7};
+        for (uint32_t r = 0; r < h; r++)
+            for (uint32_t c = 0; c < w; c++) {
+                const double u = (c + 0.5) / w * 2 - 1, v = (r + 0.5) / h * 2 - 1;
+                double y = 1 - std::fabs(u) - std::fabs(v);
+                double x = y >= 0 ? u : (1 - std::fabs(v)) * (u >= 0 ? 1.0 : -1.0);
+                double z = y >= 0 ? v : (1 - std::fabs(u)) * (v >= 0 ? 1.0 : -1.0);
+                const double n = std::sqrt(x * x + y * y + z * z);
+                x /= n; y /= n; z /= n;
+                const double up = std::sqrt(std::min(1.0, std::max(0.0, y)));
+                const double cs = x * sun[0] + y * sun[1] + z * sun[2];
+                const double disc = std::min(1.0, std::max(0.0, (cs - c4) / (c2 - c4)));
+                for (int k = 0; k < 3; k++)
+                    rgb[3 * ((size_t)r * w + c) + k] = (float)((y >= 0 ? horizon[k] + (zenith[k] - horizon[k]) * up : ground[k]) + disc * sun_scale * tint[k]);
+            }
+        return from_rgb(table, rgb, w, h);
+    }
+};
+
 // scene.rs:22-28
 class Scene {
   public:
@@ -70,6 +119,7 @@ class Scene {
     std::vector<Light> lights;
     std::vector<Bsdf> materials;
     std::vector<Prim> primitives;
+    EnvMap env_map;  // scene.rs:27 (`_env_map`); width 0 = none, as in the reference
 
     void add_light(Sphere g, Spectrum light) {  // scene.rs:71-78
         lights.push_back(Light{light, (uint32_t)primitives.size()});
@@ -135,7 +185,11 @@ class Scene {
         std::vector<iris_bsdf> bsdfs;
         std::vector<iris_spectrum> spectra;
         std::vector<iris_light> lights;
-        iris_scene_desc desc() const {
+        EnvMap env_map;
+        iris_envmap_desc env_desc;  // desc() points at it
+        iris_scene_desc desc() {
+            env_desc = iris_envmap_desc{env_map.width, env_map.height, env_map.texels.data(),
+                                        env_map.importance.empty() ? nullptr : env_map.importance.data()};
             iris_scene_desc d;
             d.n_prims = (uint32_t)spheres.size();
             d.spheres = spheres.data();
@@ -147,7 +201,7 @@ class Scene {
             d.spectra = spectra.data();
             d.n_lights = (uint32_t)lights.size();
             d.lights = lights.data();
-            d.env_map = nullptr;  // Scene._env_map (scene.rs:27): the reference never fills it
+            d.env_map = env_map.width ? &env_desc : nullptr;  // Scene._env_map (scene.rs:27): the reference never fills it
             return d;
         }
     };
@@ -166,6 +220,7 @@ class Scene {
             f.prim_material.push_back(p.material);
             f.prim_light.push_back(p.light);
         }
+        f.env_map = env_map;
         return f;
     }
 };

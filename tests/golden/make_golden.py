@@ -11,6 +11,9 @@
    oracle in ORC_TRIG_IRIS mode (the mode the GPU matches bit for bit).  They let the GPU tests compare
    against committed data as well as against the live oracle.
 
+3. film_s3env_24x24x8.npz -- the glossy/dielectric scene under a 16x16 environment map (docs/SPEC.md section 6):
+   the map's texels and importance, its sampling tables and the oracle's film.
+
 (The Sobol direction-vector fixture sobol_plain_256idx_256dim.npz is written by tools/gen_tables.py.)
 """
 import json
@@ -134,6 +137,19 @@ def main():
         radiance=np.array([list(t.radiance) for t in tr], np.float32), xyz=np.array([list(t.xyz) for t in tr], np.float32),
         n_hits=np.array([t.n_hits for t in tr], np.uint32), draws=np.array([t.draws for t in tr], np.uint32),
         hit_prim=np.array([list(t.hit_prim[:16]) for t in tr], np.int32), hit_t=np.array([list(t.hit_t[:16]) for t in tr], np.float32))
+    # ---- environment map (docs/SPEC.md section 6): texels are stored with the film, so the fixture does not
+    # depend on how this machine's numpy evaluates the procedural sky ----
+    from iris_amd import EnvMap, UpsampleTable
+    table = UpsampleTable(os.path.join(HERE, "srgb_res16.coeff"))
+    env = EnvMap.sky(table, 16, 16)
+    sc = Scene.glossy_dielectric()
+    sc.env_map = env
+    se = O.OracleScene(sc.flatten())
+    filme, _, _, ste = se.render(cam, O.make_params(24, 24, 8, max_depth=32), nthreads=4)
+    func, cond, marg, integral = se.env_tables(16, 16)
+    np.savez_compressed(os.path.join(HERE, "film_s3env_24x24x8.npz"), film=filme, texels=env.texels, importance=env.importance,
+                        func=func, cond_cdf=cond, marg_cdf=marg, integral=np.float32(integral),
+                        stats=np.array([ste.samples, ste.bounces, ste.rays, ste.sphere_tests], np.uint64))
     print("golden fixtures written to", HERE)
 
 

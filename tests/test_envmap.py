@@ -180,7 +180,40 @@ def test_scene_without_lights_needs_an_env_map_only_for_nee(oracle):
     assert abs(film[4, 4, 1] - 1.4) < 0.1 and abs(film[0, 0, 1] - 2.0) < 0.1
 
 
+def golden_env_scene():
+    from iris_amd import EnvMap, Scene
+    g = np.load(os.path.join(GOLD, "film_s3env_24x24x8.npz"))
+    s = Scene.glossy_dielectric()
+    s.env_map = EnvMap(g["texels"], g["importance"])
+    return s, g
+
+
+def test_committed_env_golden_on_the_oracle_and_host_tables(iris_trig):
+    """tests/golden/film_s3env_24x24x8.npz (made by tests/golden/make_golden.py): the oracle reproduces the
+    committed film and the product's host-side table builder reproduces the committed tables."""
+    s, g = golden_env_scene()
+    func, cond, marg, integral = s.env_map.tables()
+    assert np.array_equal(bits(func), bits(g["func"])) and np.array_equal(bits(cond), bits(g["cond_cdf"]))
+    assert np.array_equal(bits(marg), bits(g["marg_cdf"])) and bits(integral) == bits(g["integral"])
+    osc = iris_trig.OracleScene(s.flatten())
+    cam = iris_trig.camera_new([0, 0, 0], np.float32(1.0))
+    film, _, _, st = osc.render(cam, iris_trig.make_params(24, 24, 8, max_depth=32), nthreads=4)
+    assert np.array_equal(bits(film), bits(g["film"]))
+    assert [st.samples, st.bounces, st.rays, st.sphere_tests] == [int(v) for v in g["stats"]]
+
+
 # ---------------------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+def test_env_film_matches_committed_golden(gpu):
+    from iris_amd import Render
+    s, g = golden_env_scene()
+    gpu.upload(s)
+    film = gpu.render_film(Render(24, 24, 8, s, max_depth=32))
+    assert np.array_equal(bits(film), bits(g["film"]))
+    gs = gpu.stats()
+    assert [gs.samples, gs.bounces, gs.rays, gs.sphere_tests] == [int(v) for v in g["stats"]]
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene_name,integrator,max_depth", [

@@ -467,3 +467,16 @@ def test_cpp_host_driver_film_equals_python_path(gpu, tmp_path):
     subprocess.run([cli, "--width", "80", "--height", "48", "--spp", "6", "--gpus", "2", "--share-device", "--out", pfm], check=True, capture_output=True)
     img2 = np.frombuffer(open(pfm, "rb").read(), np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
     assert np.allclose(img2, want, rtol=1e-5, atol=1e-6)
+    # Scene._env_map through the C++ mirror: a uniform white map (no table needed) and the procedural sky
+    from iris_amd import EnvMap
+    s_env = Scene.dummy()
+    s_env.env_map = EnvMap.constant(1.0)
+    gpu.upload(s_env)
+    want_env = film_to_rgb(gpu.render_film(Render(80, 48, 6, s_env)))
+    subprocess.run([cli, "--width", "80", "--height", "48", "--spp", "6", "--env", "white", "--out", pfm], check=True, capture_output=True)
+    img3 = np.frombuffer(open(pfm, "rb").read(), np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
+    assert np.array_equal(bits(img3), bits(want_env))
+    subprocess.run([cli, "--width", "80", "--height", "48", "--spp", "6", "--env", "sky", "--env-size", "64", "--table",
+                    os.path.join(GOLD, "srgb_res16.coeff"), "--scene", "glossy", "--max-depth", "32", "--out", pfm], check=True, capture_output=True)
+    img4 = np.frombuffer(open(pfm, "rb").read(), np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
+    assert np.isfinite(img4).all() and img4[0, 0].min() > 0.1  # the sky is visible in the corner
