@@ -149,7 +149,7 @@ def main():
                          "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / args.steps / max(1, st.chunks), 3),
                          "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters)"},
             "rays_per_s": round(st.rays / (kernel_ms / args.steps * 1e-3), 1) if kernel_ms else None,
-            "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests},
+            "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests, "bvh_depth": st.bvh_depth},
         }
         if world == 1 and not args.no_cpu_baseline:
             n_threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))

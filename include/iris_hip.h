@@ -141,7 +141,7 @@ typedef struct {
     uint32_t launches;     /* path-tracing kernel launches */
     uint32_t chunks;       /* sample-range chunks the render was split into */
     uint32_t kernel;       /* which kernel traced the paths: enum iris_kernel_variant */
-    uint32_t reserved;
+    uint32_t bvh_depth;    /* levels of the scene's hierarchy (0: none; the scans test every sphere) */
 } iris_stats;
 
 enum iris_kernel_variant {

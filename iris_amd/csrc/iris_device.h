@@ -259,7 +259,7 @@ IRIS_DEV uint2 sobol_lut_entry(uint32_t e) {
 IRIS_DEV void sobol_sample_4d(SobolLds lut, uint32_t index, uint32_t set, uint32_t seed, float out[4]) {
     uint32_t shuffled_rev = lk_scramble(__builtin_bitreverse32(index), lowbias32(seed));
     uint32_t x01 = 0u, x23 = 0u;
-    if (set < IRIS_SOBOL_LUT_SETS) {
+    if (lut != nullptr && set < IRIS_SOBOL_LUT_SETS) {  // lut == nullptr: the kernel keeps no nibble table (hierarchy variant)
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {
             uint2 v = lut[(set * 4u + j) * 16u + ((shuffled_rev >> (28u - 4u * j)) & 15u)];
@@ -566,18 +566,12 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, f
     uint32_t ref = bvh_ref(root_lo, root_hi);
     uint32_t sp = 0u;
     bool have = box_entry(root_lo, root_hi, ray.o, inv, closest_t) < __builtin_inff();
+    // "while-while": every lane first descends through inner nodes until it holds a leaf (or has nothing left),
+    // then the lanes of the wave test their leaves together -- the two kinds of work are not interleaved lane by
+    // lane, which is what keeps the lanes of a wave on the same instructions.
     for (;;) {
-        if (!have) {
-            if (sp == 0u) break;
-            sp--;
-            ref = stack[sp * IRIS_BLOCK];
-        }
-        have = false;
-        const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
-        if (count != 0u) {
-            for (uint32_t k = 0; k < count; k++) bvh_sphere_test(sc, first + k, ray, a, closest_t, closest);
-            n_tests += count;
-        } else {
+        while (have && (ref >> 29) == 0u) {
+            const uint32_t first = ref & 0x1fffffffu;
             const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
             const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];
             const float tl = box_entry(l0, l1, ray.o, inv, closest_t), tr = box_entry(r0, r1, ray.o, inv, closest_t);
@@ -590,8 +584,22 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, f
                     sp++;
                 }
                 ref = left_first ? ref_l : ref_r;
-                have = true;
+            } else if (sp != 0u) {
+                sp--;
+                ref = stack[sp * IRIS_BLOCK];
+            } else {
+                have = false;
             }
+        }
+        if (!have) break;
+        const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
+        for (uint32_t k = 0; k < count; k++) bvh_sphere_test(sc, first + k, ray, a, closest_t, closest);
+        n_tests += count;
+        if (sp != 0u) {
+            sp--;
+            ref = stack[sp * IRIS_BLOCK];
+        } else {
+            have = false;
         }
     }
     tests += n_tests;

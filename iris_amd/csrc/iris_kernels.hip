@@ -323,20 +323,28 @@ k_wavefront(WfArgs a) {
 // synchronisation is needed.
 enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u };
 constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
-constexpr uint32_t PQ_CAP = 104;    // < PQ_CAP - 63 queued when a generate phase starts, <= 64 added by it
-constexpr uint32_t PQ_LOW = PQ_CAP - 63;  // generate while fewer records than this are queued
+// BVH (compile-time): the scene has a hierarchy.  Traversal is bound by the latency of dependent L2 reads, so
+// what counts is resident waves, and LDS is what limits them: the per-lane traversal stacks take 1 KiB per
+// level.  That variant therefore does without the Sobol nibble table (direction vectors come from the constant
+// table in global memory, bit by bit) and keeps a shorter primary-hit queue, which buys the third workgroup per
+// CU; the list-scan variant compiles no traversal code at all.
+template <bool BVH> struct PqGeom { static constexpr uint32_t CAP = BVH ? 80u : 104u; };  // < CAP - 63 queued when a generate phase starts, <= 64 added by it
 
-template <int INTEG, int CLS>
+template <int INTEG, int CLS, bool BVH>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_regwave(WfArgs a) {
+    constexpr uint32_t PQ_CAP = PqGeom<BVH>::CAP;
+    constexpr uint32_t PQ_LOW = PQ_CAP - 63u;  // generate while fewer records than this are queued
     extern __shared__ float4 sphere_win[];
-    __shared__ uint2 sobol_lds[IRIS_SOBOL_LUT_ENTRIES];
+    __shared__ uint2 sobol_tab[BVH ? 1 : IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ uint32_t primq[BLOCK / 64][PQ_FIELDS][PQ_CAP];
     __shared__ BlockShared bs;
-    stage_tables(sobol_lds);
+    if (!BVH) stage_tables(sobol_tab);
+    const SobolLds sobol_lds = BVH ? nullptr : sobol_tab;
     DrawRing ring = ring_lds + threadIdx.x;
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
-    st.resident = true;  // launched only when the whole list is in the window: no barrier inside the scans
+    st.bvh = BVH;        // compile-time: the other scan's code is not compiled in
+    st.resident = !BVH;  // launched only when the whole list is in the window (or with a hierarchy): no barrier inside the scans
     if (threadIdx.x == 0) {
         block_range(a, bs.cursor, bs.w_end);
         bs.qn = 0u;
@@ -647,6 +655,7 @@ struct iris_ctx {
     int64_t mode = 0;             // 0 auto, 1 pool/queue kernels, 2 register-resident kernel
     int64_t reg_blocks_per_cu = 32;  // register-resident kernel: more workgroups than fit, for a short tail
     int64_t bvh_min_prims = 65;   // build a hierarchy for scenes with at least this many spheres (0: never)
+    int64_t bvh_leaf = 4;         // spheres per leaf of the hierarchy (1..7)
     int64_t specialize = 1;       // 1: use the kernel compiled for the scene's class; 0: always the general kernel
     int scene_class = IRIS_CLS_GENERAL;
     // scene
@@ -683,7 +692,7 @@ struct Bvh {
     uint32_t depth = 0;
     uint32_t n_big = 0;  // the last n_big leaf-ordered spheres are outside the tree
 };
-constexpr uint32_t BVH_LEAF = 4;  // <= 7: a node reference keeps the count in three bits, the first sphere in 29
+uint32_t BVH_LEAF = 4;  // <= 7: a node reference keeps the count in three bits, the first sphere in 29 (option bvh_leaf)
 float4 with_bits(float x, float y, float z, uint32_t w) {
     float f;
     std::memcpy(&f, &w, 4);
@@ -789,7 +798,8 @@ void build_bvh_node(const iris_sphere *sp, std::vector<uint32_t> &order, uint32_
 // level of their branch; they are kept out of the tree and tested first, one by one (at most BVH_MAX_BIG).
 constexpr uint32_t BVH_MAX_BIG = 16;
 // false: no hierarchy (non-finite geometry, nothing left for a tree) -- the list scan is used instead
-bool build_bvh(const iris_sphere *sp, uint32_t n, Bvh &out) {
+bool build_bvh(const iris_sphere *sp, uint32_t n, uint32_t leaf, Bvh &out) {
+    BVH_LEAF = leaf;
     BvhBounds cen;
     for (uint32_t i = 0; i < n; i++) {
         if (!std::isfinite(sp[i].cx) || !std::isfinite(sp[i].cy) || !std::isfinite(sp[i].cz) || !std::isfinite(sp[i].r)) return false;
@@ -944,9 +954,16 @@ int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stre
     size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
     const bool lc = c->scene_class == IRIS_CLS_LAMBERT_CONSTANT, env = c->scene_class == IRIS_CLS_GENERAL_ENV;
     if (use_register_kernel(c)) {
-        if (lc) hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_LAMBERT_CONSTANT>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
-        else if (env) hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_GENERAL_ENV>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
-        else hipLaunchKernelGGL((k_regwave<INTEG, IRIS_CLS_GENERAL>), dim3(blocks), dim3(BLOCK), dyn, stream, a);
+        const bool bvh = c->sc.n_bvh_nodes != 0u;
+#define IRIS_LAUNCH_REG(CLS_)                                                                                                   \
+    do {                                                                                                                        \
+        if (bvh) hipLaunchKernelGGL((k_regwave<INTEG, CLS_, true>), dim3(blocks), dim3(BLOCK), dyn, stream, a);                 \
+        else hipLaunchKernelGGL((k_regwave<INTEG, CLS_, false>), dim3(blocks), dim3(BLOCK), dyn, stream, a);                    \
+    } while (0)
+        if (lc) IRIS_LAUNCH_REG(IRIS_CLS_LAMBERT_CONSTANT);
+        else if (env) IRIS_LAUNCH_REG(IRIS_CLS_GENERAL_ENV);
+        else IRIS_LAUNCH_REG(IRIS_CLS_GENERAL);
+#undef IRIS_LAUNCH_REG
         HIP_TRY(c, hipGetLastError());
         c->stats.launches += 1;
         return IRIS_OK;
@@ -1080,6 +1097,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     c->stats.sphere_tests = h[3];
     c->stats.kernel_ms = trace_ms;
     c->stats.resolve_ms = resolve_ms;
+    c->stats.bvh_depth = c->bvh_depth;
     c->stats.kernel = reg ? IRIS_KERNEL_REGISTER : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED);
     return IRIS_OK;
 }
@@ -1147,6 +1165,9 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "bvh_min_prims") {
         if (value < 0) return fail(c, IRIS_E_ARG, "bvh_min_prims must be >= 0");
         c->bvh_min_prims = value;  // takes effect at the next iris_scene_upload
+    } else if (k == "bvh_leaf") {
+        if (value < 1 || value > 7) return fail(c, IRIS_E_ARG, "bvh_leaf out of range [1, 7]");
+        c->bvh_leaf = value;  // takes effect at the next iris_scene_upload
     } else if (k == "specialize") {
         c->specialize = value ? 1 : 0;
         if (c->scene_class != IRIS_CLS_GENERAL_ENV)
@@ -1222,7 +1243,7 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     c->bvh_depth = 0;
     if (c->bvh_min_prims > 0 && (int64_t)s->n_prims >= c->bvh_min_prims) {
         Bvh bvh;
-        if (build_bvh(s->spheres, s->n_prims, bvh)) {
+        if (build_bvh(s->spheres, s->n_prims, (uint32_t)c->bvh_leaf, bvh)) {
             HIP_TRY(c, up(&c->d_bvh_nodes, bvh.nodes.data(), sizeof(float4) * bvh.nodes.size()));
             HIP_TRY(c, up(&c->d_bvh_spheres, bvh.spheres.data(), sizeof(float4) * bvh.spheres.size()));
             HIP_TRY(c, up(&c->d_bvh_prim, bvh.prim.data(), sizeof(uint32_t) * bvh.prim.size()));
