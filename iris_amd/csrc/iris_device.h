@@ -422,6 +422,7 @@ struct SceneDev {
     const int2 *prim_info;      // (material_index, light_index), -1 = None
     const iris_bsdf *bsdfs;
     const iris_spectrum *spectra;
+    const float *spec_over_pi;  // per spectrum: c0 / PI for a constant spectrum (the IEEE quotient, formed once on the host)
     const iris_light *lights;
     uint32_t n_prims, n_lights;
     // Bounding-volume hierarchy over the spheres (long lists only; n_bvh_nodes == 0: none).  Node k is two
@@ -453,6 +454,26 @@ IRIS_DEV V3 shading_to_world(const Hit &h, V3 s) {
 
 // sphere.rs:26-35 + :53: the ray parameter of the first root > 0, or a negative number for None.
 // `sp` is a staged sphere: (cx, cy, cz, radius * radius) -- the product the reference forms at sphere.rs:29.
+// sphere.rs:31-35, :53 take `temp = (-half_b - root) / a`, and `(-half_b + root) / a` if that is not > 0.
+// For 0.5 < a < 1.5 (a = d.d of a normalised direction; `a_unit`) the sign test can be made on the numerators:
+// num / a > 0 <=> num > 0, because a positive quotient is above half of the smallest denormal and cannot round
+// to zero, and a non-positive (or NaN) numerator gives a quotient that is not > 0.  So the root is chosen first
+// and only the chosen numerator is divided -- the same value the reference computes -- and a sphere wholly behind
+// the origin (both numerators <= 0: the sphere a bounce ray starts on, in every scan) costs no division at all.
+// Returns the first root > 0, or a value that is not > 0.
+IRIS_DEV bool a_is_unit(float a) { return a > 0.5f && a < 1.5f; }
+IRIS_DEV float first_positive_root(float half_b, float root, float a, bool a_unit) {
+    const float n1 = -half_b - root, n2 = -half_b + root;
+    if (a_unit) {
+        const float num = n1 > 0.0f ? n1 : n2;
+        float temp = -1.0f;
+        if (num > 0.0f) temp = num / a;
+        return temp;
+    }
+    float temp = n1 / a;
+    if (!(temp > 0.0f)) temp = n2 / a;
+    return temp;
+}
 IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
     V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
     float half_b = dot(ray.d, oc);
@@ -460,9 +481,7 @@ IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
     float discrim = half_b * half_b - a * c;
     float t = -1.0f;
     if (discrim > 0.0f) {
-        float root = rsqrt_exact(discrim);
-        float temp = (-half_b - root) / a;
-        if (!(temp > 0.0f)) temp = (-half_b + root) / a;
+        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_is_unit(a));
         if (temp > 0.0f) t = temp;
     }
     return t;
@@ -470,15 +489,13 @@ IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
 // The same test inside a closest-hit scan: `if t < closest_t && t > 0 { closest = .. }` (scene.rs:123-126).
 // Almost every test of a long list ends at `discrim > 0` being false, so the bookkeeping of the closest
 // hit lives inside that branch and the common path is the discriminant alone.
-IRIS_DEV void sphere_test(float4 sp, const Ray &ray, float a, int index, float &closest_t, int &closest) {
+IRIS_DEV void sphere_test(float4 sp, const Ray &ray, float a, bool a_unit, int index, float &closest_t, int &closest) {
     V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
     float half_b = dot(ray.d, oc);
     float c = len_squared(oc) - sp.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {
-        float root = rsqrt_exact(discrim);
-        float temp = (-half_b - root) / a;
-        if (!(temp > 0.0f)) temp = (-half_b + root) / a;
+        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_unit);
         if (temp > 0.0f && temp < closest_t) { closest_t = temp; closest = index; }
     }
 }
@@ -511,15 +528,18 @@ struct SphereStage {
 
 // One pass over `n` staged spheres (n real ones, followed by fillers up to a multiple of IRIS_SCAN_PAD),
 // B at a time: the B LDS reads of a batch are issued together, so their latency is paid once per batch.
+// n is wave-uniform, so the bound check of the last batch is a scalar branch and a filler costs no test.
 template <uint32_t B>
 IRIS_DEV void scan_window(const float4 *win, uint32_t n, uint32_t base, const Ray &ray, float a, float &closest_t, int &closest) {
+    const bool a_unit = a_is_unit(a);
     for (uint32_t i = 0; i < n; i += B) {
         float4 sp[B];
 #pragma unroll
         for (uint32_t k = 0; k < B; k++) sp[k] = win[i + k];
 #pragma unroll
         for (uint32_t k = 0; k < B; k++) {
-            sphere_test(sp[k], ray, a, (int)(base + i + k), closest_t, closest);
+            if (__builtin_amdgcn_readfirstlane(i + k) < __builtin_amdgcn_readfirstlane(n))
+                sphere_test(sp[k], ray, a, a_unit, (int)(base + i + k), closest_t, closest);
         }
     }
 }
@@ -548,9 +568,7 @@ IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray,
     float c = len_squared(oc) - sp4.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {  // sphere.rs:31-35, :53
-        float root = rsqrt_exact(discrim);
-        float temp = (-half_b - root) / a;
-        if (!(temp > 0.0f)) temp = (-half_b + root) / a;
+        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_is_unit(a));
         if (temp > 0.0f && (temp < closest_t || (temp == closest_t && index < closest))) { closest_t = temp; closest = index; }
     }
 }
@@ -740,6 +758,13 @@ IRIS_DEV float ggx_pdf(V3 wo, V3 wh, float ax, float ay) {  // ggx.rs:61-64
 // ---------------------------------------------------------------- BSDFs (bsdf/*.rs)
 IRIS_DEV V3 reflect(V3 wo, V3 n) { return (-wo) + (2.0f * dot(wo, n)) * n; }  // microfacet.rs:91-93
 
+// lambertian.rs:24-31, :43: albedo.evaluate(lambda) / PI.  For a constant spectrum the four quotients are one
+// value that does not depend on the path: iris_scene_upload forms it once (the same correctly rounded f32
+// division), so the three evaluations of a bounce cost a load instead of IEEE divisions.
+IRIS_DEV F4 lambertian_value(const SceneDev &sc, const iris_bsdf &b, F4 wl, bool mono) {
+    if (mono || sc.spectra[b.spec_a].kind == IRIS_SPEC_CONSTANT) return splat(sc.spec_over_pi[b.spec_a]);
+    return spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / PI_F;
+}
 IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl, bool mono) {  // microfacet.rs:33-57
     float cos_theta_o = fabs_(cos_theta(wo));
     float cos_theta_i = fabs_(cos_theta(wi));
@@ -754,7 +779,7 @@ IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V
     return (((spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) * d) * g) * f) / (4.0f * cos_theta_o * cos_theta_i);
 }
 IRIS_DEV F4 bsdf_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl, bool mono) {
-    if (b.kind == IRIS_BSDF_LAMBERTIAN) return spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / PI_F;  // lambertian.rs:24-31
+    if (b.kind == IRIS_BSDF_LAMBERTIAN) return lambertian_value(sc, b, wl, mono);  // lambertian.rs:24-31
     if (b.kind == IRIS_BSDF_MICROFACET) return microfacet_evaluate(sc, b, wi, wo, wl, mono);
     return splat(0.0f);  // specular.rs:26-33, fresnel.rs:37-44
 }
@@ -776,7 +801,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         V3 wi = cosine_unit_hemisphere(r1, r2);
         wi = same_hemisphere(wo, wi) ? wi : -wi;
         wi_out = wi;
-        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / PI_F;
+        val_out = lambertian_value(sc, b, wl, mono);
         pdf_out = splat(fabs_(cos_theta(wi)) / PI_F);
     } else if (b.kind == IRIS_BSDF_MICROFACET) {  // microfacet.rs:65-88
         V3 wh = ggx_sample(wo, b.p0, b.p1, ring, smp);

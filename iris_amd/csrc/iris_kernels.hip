@@ -662,7 +662,7 @@ struct iris_ctx {
     bool have_scene = false;
     bool scene_is_lambert_constant = false;
     SceneDev sc = {};
-    void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr;
+    void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr, *d_spec_over_pi = nullptr;
     void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr;
     void *d_env_texels = nullptr, *d_env_func = nullptr, *d_env_cond = nullptr, *d_env_marg = nullptr;
     uint32_t bvh_depth = 0;
@@ -840,6 +840,12 @@ bool build_bvh(const iris_sphere *sp, uint32_t n, uint32_t leaf, Bvh &out) {
         out.spheres[i] = make_float4(s.cx, s.cy, s.cz, s.r * s.r);
     }
     return true;
+}
+
+// one correctly rounded f32 division on the host (what the kernels' `/` is: -ffp-contract=off, IEEE divide)
+float iris_f32_div(float a, float b) {
+    volatile float x = a, y = b;
+    return x / y;
 }
 
 int fail(iris_ctx *ctx, int code, const std::string &msg) {
@@ -1132,7 +1138,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_pools(c);
-    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
+    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc);
@@ -1212,7 +1218,8 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
         em = nullptr;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights);
+    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi);
+    c->d_spec_over_pi = nullptr;
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     c->d_env_texels = c->d_env_func = c->d_env_cond = c->d_env_marg = nullptr;
@@ -1232,6 +1239,10 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     HIP_TRY(c, up(&c->d_bsdfs, s->bsdfs, sizeof(iris_bsdf) * s->n_bsdfs));
     HIP_TRY(c, up(&c->d_spectra, s->spectra, sizeof(iris_spectrum) * s->n_spectra));
     HIP_TRY(c, up(&c->d_lights, s->lights, sizeof(iris_light) * s->n_lights));
+    std::vector<float> over_pi(std::max<uint32_t>(s->n_spectra, 1u), 0.0f);
+    for (uint32_t i = 0; i < s->n_spectra; i++) over_pi[i] = iris_f32_div(s->spectra[i].c0, PI_F);  // lambertian.rs:30: albedo / PI, one IEEE division
+    HIP_TRY(c, up(&c->d_spec_over_pi, over_pi.data(), sizeof(float) * over_pi.size()));
+    c->sc.spec_over_pi = (const float *)c->d_spec_over_pi;
     c->sc.spheres = (const float4 *)c->d_spheres;
     c->sc.prim_info = (const int2 *)c->d_prim_info;
     c->sc.bsdfs = (const iris_bsdf *)c->d_bsdfs;
