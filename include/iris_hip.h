@@ -37,6 +37,7 @@ extern "C" {
 #define IRIS_E_HIP (-2)   /* a HIP runtime call failed */
 #define IRIS_E_STATE (-3) /* call out of order (e.g. render before scene upload) */
 #define IRIS_E_LIMIT (-4) /* a documented size limit was exceeded */
+#define IRIS_E_RCCL (-5)  /* librccl.so could not be loaded or an RCCL call failed */
 
 /* enum Bsdf, bsdf/mod.rs:49-55 (same order) */
 enum iris_bsdf_kind {
@@ -247,6 +248,22 @@ int iris_envmap_texels_from_rgb(const iris_upsample_table *table, const float *r
 int iris_render(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params, float *out_xyz);
 int iris_render_device(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params,
                        float *d_out_xyz, void *stream);
+
+/* The exchange step of a multi-GPU render.  The reference has one shared film behind a RwLock that the
+ * worker threads copy their tiles into (main.rs:39, tile.rs:115-121); here each of n GPUs (one context each,
+ * all in this process, all on different devices) has rendered a disjoint range of sample indices
+ * (spp_begin/spp_count) into its own DEVICE film d_films[i] of n_floats floats, and this call sums them in place
+ * with one ncclAllReduce(sum, f32) per GPU over xGMI: every film ends up holding the whole render (equal to the
+ * single-GPU film up to f32 re-association of the per-pixel sum).  RCCL is loaded on first use; the
+ * communicators are kept until iris_allreduce_shutdown().  Calls must not overlap. */
+int iris_allreduce_films(iris_ctx *const *ctxs, int n, float *const *d_films, size_t n_floats);
+void iris_allreduce_shutdown(void);
+/* The whole multi-GPU render in one call -- the worker-thread pool and shared film of main.rs:87-107 across n
+ * GPUs: context i (every one holding the same scene) renders sample indices
+ * [spp_begin + i*spp_count/n, spp_begin + (i+1)*spp_count/n) of every pixel from its own host thread into a
+ * device film, iris_allreduce_films sums them, and the total is copied to out_xyz (HOST, width*height*3).
+ * Contexts that share a device (a rehearsal on a one-GPU machine) are summed on the host instead. */
+int iris_render_multi(iris_ctx *const *ctxs, int n, const iris_camera *camera, const iris_render_params *params, float *out_xyz);
 
 /* XYZ -> linear RGB, clamped at 0: Xyz::to_rgb_hdr (color.rs:36-41) + the clamp of tile.rs:108-109.
  * Host arrays of 3*n_pixels floats. */

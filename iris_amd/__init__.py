@@ -9,7 +9,7 @@ spectral renderer, behind the C ABI of include/iris_hip.h.
 The compute path is libiris_hip.so (hand-written HIP); there is no CPU fallback.
 """
 from .ffi import IrisError  # noqa: F401
-from .render import Camera, HipWavefront, Render, film_to_rgb  # noqa: F401
+from .render import Camera, HipWavefront, Render, allreduce_films, film_to_rgb, render_film_multi  # noqa: F401
 from .scene import (  # noqa: F401
     HWSS_NAIVE, HWSS_SLOW, SWSS_NAIVE, SWSS_SLOW, INTEGRATORS, ConstantSpectrum, EnvMap, FresnelBsdf, LambertianBsdf,
     MicrofacetBsdf, NullBsdf, Scene, SpecularBsdf, Sphere, UpsampledHdrSpectrum, UpsampledSpectrum, UpsampleTable,

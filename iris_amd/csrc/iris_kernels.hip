@@ -15,8 +15,11 @@
 //   * Resolve: per pixel, the per-sample XYZ values are summed in ascending sample order (the order of
 //     tile.rs:144-163) and scaled by 1/spp.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1322,6 +1325,182 @@ int iris_get_stats(const iris_ctx *c, iris_stats *out) {
     if (!c || !out) return IRIS_E_ARG;
     *out = c->stats;
     return IRIS_OK;
+}
+
+// ---- the exchange step of a multi-GPU render: sum the partial films over xGMI (RCCL) ----
+// One process drives n GPUs (one iris_ctx each, e.g. from n host threads); every GPU has rendered a disjoint
+// range of sample indices into its own device film.  RCCL is loaded at first use (dlopen), so a single-GPU
+// caller never needs it, and the communicators are created once per device list and kept.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::vector<int> devices;
+    std::vector<void *> comms;
+    std::vector<hipStream_t> streams;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;  // ncclDataType_t / ncclRedOp_t of rccl.h
+
+bool rccl_load(std::string &err) {
+    if (g_rccl.lib) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+    auto sym = [&](const char *n) { return dlsym(g_rccl.lib, n); };
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.GetErrorString) {
+        err = "librccl.so lacks an expected symbol";
+        dlclose(g_rccl.lib);
+        g_rccl.lib = nullptr;
+        return false;
+    }
+    return true;
+}
+void rccl_drop_comms() {
+    for (size_t i = 0; i < g_rccl.comms.size(); i++) {
+        (void)hipSetDevice(g_rccl.devices[i]);
+        if (g_rccl.comms[i]) (void)g_rccl.CommDestroy(g_rccl.comms[i]);
+        if (g_rccl.streams[i]) (void)hipStreamDestroy(g_rccl.streams[i]);
+    }
+    g_rccl.comms.clear(); g_rccl.streams.clear(); g_rccl.devices.clear();
+}
+}  // namespace
+
+int iris_allreduce_films(iris_ctx *const *ctxs, int n, float *const *d_films, size_t n_floats) {
+    if (!ctxs || n < 1 || !ctxs[0]) return IRIS_E_ARG;
+    iris_ctx *c0 = ctxs[0];
+    if (!d_films) return fail(c0, IRIS_E_ARG, "d_films is NULL");
+    std::vector<int> devices((size_t)n);
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !d_films[i]) return fail(c0, IRIS_E_ARG, "NULL context or film");
+        devices[i] = ctxs[i]->device;
+        for (int j = 0; j < i; j++)
+            if (devices[j] == devices[i]) return fail(c0, IRIS_E_ARG, "two contexts on one device: RCCL needs one rank per GPU (sum such films on the host)");
+    }
+    if (n_floats == 0) return IRIS_OK;
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    std::string err;
+    if (!rccl_load(err)) return fail(c0, IRIS_E_RCCL, err);
+#define RCCL_TRY(expr)                                                                                              \
+    do {                                                                                                             \
+        int r_ = (expr);                                                                                             \
+        if (r_ != 0) return fail(c0, IRIS_E_RCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));           \
+    } while (0)
+    if (g_rccl.devices != devices) {  // first call, or another set of GPUs
+        rccl_drop_comms();
+        g_rccl.comms.assign((size_t)n, nullptr);
+        g_rccl.streams.assign((size_t)n, nullptr);
+        g_rccl.devices = devices;
+        int r = g_rccl.CommInitAll(g_rccl.comms.data(), n, devices.data());
+        if (r != 0) { g_rccl.devices.clear(); g_rccl.comms.clear(); g_rccl.streams.clear(); return fail(c0, IRIS_E_RCCL, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(c0, hipSetDevice(devices[i]));
+            HIP_TRY(c0, hipStreamCreateWithFlags(&g_rccl.streams[i], hipStreamNonBlocking));
+        }
+    }
+    for (int i = 0; i < n; i++) {  // the films were written on other streams: make sure they are complete
+        HIP_TRY(c0, hipSetDevice(devices[i]));
+        HIP_TRY(c0, hipDeviceSynchronize());
+    }
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(c0, hipSetDevice(devices[i]));
+        int r = g_rccl.AllReduce(d_films[i], d_films[i], n_floats, NCCL_FLOAT32, NCCL_SUM, g_rccl.comms[i], g_rccl.streams[i]);
+        if (r != 0) { (void)g_rccl.GroupEnd(); return fail(c0, IRIS_E_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r)); }
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+#undef RCCL_TRY
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(c0, hipSetDevice(devices[i]));
+        HIP_TRY(c0, hipStreamSynchronize(g_rccl.streams[i]));
+    }
+    return IRIS_OK;
+}
+
+// The whole multi-GPU render in one call: what main.rs:87-107 does with worker threads and one shared film.
+int iris_render_multi(iris_ctx *const *ctxs, int n, const iris_camera *cam, const iris_render_params *p, float *out_xyz) {
+    if (!ctxs || n < 1 || !ctxs[0]) return IRIS_E_ARG;
+    iris_ctx *c0 = ctxs[0];
+    int rc;
+    if ((rc = check_params(c0, p))) return rc;
+    if (!cam || !out_xyz) return fail(c0, IRIS_E_ARG, "camera or out_xyz is NULL");
+    bool distinct = true;
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return fail(c0, IRIS_E_ARG, "NULL context");
+        for (int j = 0; j < i; j++) distinct = distinct && ctxs[j]->device != ctxs[i]->device;
+    }
+    const size_t n_floats = (size_t)p->width * p->height * 3;
+    std::vector<float *> d_films((size_t)n, nullptr);
+    std::vector<int> rcs((size_t)n, IRIS_OK);
+    auto cleanup = [&]() {
+        for (int i = 0; i < n; i++) {
+            (void)hipSetDevice(ctxs[i]->device);
+            dev_free(d_films[i]);
+        }
+    };
+    for (int i = 0; i < n; i++) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipMalloc((void **)&d_films[i], n_floats * sizeof(float)) != hipSuccess) {
+            cleanup();
+            return fail(c0, IRIS_E_HIP, "hipMalloc of a device film failed");
+        }
+    }
+    {   // one host thread per GPU, each rendering its share of the sample indices of every pixel
+        std::vector<std::thread> threads;
+        for (int i = 0; i < n; i++) {
+            threads.emplace_back([&, i]() {
+                iris_render_params q = *p;
+                const uint64_t b = (uint64_t)p->spp_count * (uint64_t)i / (uint64_t)n, e = (uint64_t)p->spp_count * (uint64_t)(i + 1) / (uint64_t)n;
+                q.spp_begin = p->spp_begin + (uint32_t)b;
+                q.spp_count = (uint32_t)(e - b);
+                rcs[i] = render_impl(ctxs[i], cam, &q, d_films[i], nullptr);
+            });
+        }
+        for (auto &t : threads) t.join();
+    }
+    for (int i = 0; i < n; i++)
+        if (rcs[i] != IRIS_OK) {
+            if (i != 0) c0->err = "context " + std::to_string(i) + ": " + ctxs[i]->err;
+            cleanup();
+            return rcs[i];
+        }
+    rc = IRIS_OK;
+    if (n > 1 && distinct) {
+        rc = iris_allreduce_films(ctxs, n, d_films.data(), n_floats);  // the exchange step, over xGMI
+        if (rc == IRIS_OK && (hipSetDevice(c0->device) != hipSuccess || hipMemcpy(out_xyz, d_films[0], n_floats * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess))
+            rc = fail(c0, IRIS_E_HIP, "hipMemcpy of the film failed");
+    } else {  // one GPU, or several contexts sharing a GPU (a rehearsal): the partial films are summed on the host, in context order
+        std::vector<float> part(n_floats);
+        for (int i = 0; i < n && rc == IRIS_OK; i++) {
+            if (hipSetDevice(ctxs[i]->device) != hipSuccess ||
+                hipMemcpy(i == 0 ? out_xyz : part.data(), d_films[i], n_floats * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = fail(c0, IRIS_E_HIP, "hipMemcpy of a partial film failed");
+                break;
+            }
+            if (i != 0)
+                for (size_t k = 0; k < n_floats; k++) out_xyz[k] += part[k];
+        }
+    }
+    cleanup();
+    return rc;
+}
+
+void iris_allreduce_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) rccl_drop_comms();
 }
 
 // ---- debug / parity entry points ----

@@ -16,7 +16,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "iris_scene.hpp"
@@ -206,25 +205,17 @@ int main(int argc, char **argv) {
     std::printf("Starting render, %ux%u@%uspp...\n", width, height, spp);  // main.rs:80-83
     const auto start = std::chrono::steady_clock::now();
     const size_t n = (size_t)width * height * 3;
-    std::vector<std::vector<float>> films((size_t)gpus, std::vector<float>(n));
-    std::vector<int> rcs((size_t)gpus, 0);
-    std::vector<std::thread> threads;
-    for (int g = 0; g < gpus; g++) {
-        threads.emplace_back([&, g]() {
-            iris_render_params p = {width, height, spp, 0u, 0u, 123456789u /* tile.rs:15 */, max_depth, min_depth, integrator};
-            p.spp_begin = (uint32_t)((uint64_t)spp * (uint64_t)g / (uint64_t)gpus);
-            p.spp_count = (uint32_t)((uint64_t)spp * (uint64_t)(g + 1) / (uint64_t)gpus) - p.spp_begin;
-            rcs[g] = iris_render(ctx[g], &camera, &p, films[g].data());
-        });
-    }
-    for (auto &t : threads) t.join();
-    for (int g = 0; g < gpus; g++)
-        if (rcs[g] != IRIS_OK) {
-            std::fprintf(stderr, "iris_render on device %d failed (%d): %s\n", device + g, rcs[g], iris_last_error(ctx[g]));
+    std::vector<std::vector<float>> films(1, std::vector<float>(n));
+    {
+        // one call: a host thread per GPU, each rendering its share of the sample indices, then the RCCL
+        // all-reduce of the device films over xGMI (host sum when the contexts share a device)
+        const iris_render_params p = {width, height, spp, 0u, spp, 123456789u /* tile.rs:15 */, max_depth, min_depth, integrator};
+        const int rc = iris_render_multi(ctx.data(), gpus, &camera, &p, films[0].data());
+        if (rc != IRIS_OK) {
+            std::fprintf(stderr, "iris_render_multi failed (%d): %s\n", rc, iris_last_error(ctx[0]));
             return 1;
         }
-    for (int g = 1; g < gpus; g++)  // partial films of disjoint sample ranges add up (include/iris_hip.h)
-        for (size_t i = 0; i < n; i++) films[0][i] += films[g][i];
+    }
     const float elapsed = std::chrono::duration<float>(std::chrono::steady_clock::now() - start).count();
     std::printf("Done in %gs (%gm ray/s)\n", elapsed, (float)((double)spp * width * height) / (1000000.0f * elapsed));  // main.rs:109-114
     uint64_t rays = 0, bounces = 0;

@@ -163,6 +163,27 @@ class HipWavefront:
         return out
 
 
+def render_film_multi(gpus, render: Render, spp_begin=0, spp_count=None):
+    """iris_render_multi: the film rendered by several HipWavefront contexts (one per GPU, each holding the
+    scene), sample indices split across them, partial films summed by one RCCL all-reduce over xGMI (on the host
+    when contexts share a GPU).  -> (H, W, 3) f32."""
+    L = ffi.load()
+    p = render.params(spp_begin, spp_count)
+    arr = (C.c_void_p * len(gpus))(*[g.ctx for g in gpus])
+    out = np.zeros((render.height, render.width, 3), np.float32)
+    rc = L.iris_render_multi(arr, len(gpus), C.byref(render.camera.c), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_float)))
+    _check(L, gpus[0].ctx, rc, "iris_render_multi")
+    return out
+
+
+def allreduce_films(gpus, device_ptrs, n_floats):
+    """iris_allreduce_films: in-place sum of one device film per context (all on different GPUs) with RCCL."""
+    L = ffi.load()
+    ctxs = (C.c_void_p * len(gpus))(*[g.ctx for g in gpus])
+    ptrs = (C.c_void_p * len(gpus))(*[C.c_void_p(p) for p in device_ptrs])
+    _check(L, gpus[0].ctx, L.iris_allreduce_films(ctxs, len(gpus), ptrs, n_floats), "iris_allreduce_films")
+
+
 def film_to_rgb(xyz):
     """Xyz::to_rgb_hdr + clamp (color.rs:36-41, tile.rs:108-109) on a (H, W, 3) film."""
     L = ffi.load()

@@ -480,3 +480,43 @@ def test_cpp_host_driver_film_equals_python_path(gpu, tmp_path):
                     os.path.join(GOLD, "srgb_res16.coeff"), "--scene", "glossy", "--max-depth", "32", "--out", pfm], check=True, capture_output=True)
     img4 = np.frombuffer(open(pfm, "rb").read(), np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
     assert np.isfinite(img4).all() and img4[0, 0].min() > 0.1  # the sky is visible in the corner
+
+
+def test_multi_gpu_entry_points_on_one_gpu(gpu, iris_trig):
+    """iris_render_multi and iris_allreduce_films as far as one GPU can exercise them: one context = the plain
+    render bit for bit; two contexts sharing the device = the spp split with the host sum (f32 re-association of
+    the per-pixel sum, rtol 2e-6 + the film's own rounding); the RCCL path itself with a single rank (loads
+    librccl, creates the communicator, runs ncclAllReduce in place: the film must come back unchanged)."""
+    import ctypes as C
+    import iris_amd
+    from iris_amd import Render, Scene
+    hip = C.CDLL("libamdhip64.so")  # the HIP runtime libiris_hip.so already loaded: plain device buffers for the test
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    scene = Scene.dummy()
+    r = Render(64, 40, 12, scene)
+    gpu.upload(scene)
+    want = gpu.render_film(r)
+    assert np.array_equal(bits(iris_amd.render_film_multi([gpu], r)), bits(want))
+    with iris_amd.HipWavefront(0) as g2, iris_amd.HipWavefront(0) as g3:
+        g2.upload(scene)
+        g3.upload(scene)
+        got = iris_amd.render_film_multi([gpu, g2, g3], r)
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
+        # sample ranges [0,4) [4,8) [8,12): the same partial films the single-context path renders
+        parts = [gpu.render_film(r, spp_begin=b, spp_count=4) for b in (0, 4, 8)]
+        assert np.array_equal(bits(got), bits((parts[0] + parts[1]) + parts[2]))
+        d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), want.nbytes) == 0
+        try:
+            with pytest.raises(iris_amd.IrisError):  # RCCL needs one rank per GPU
+                iris_amd.allreduce_films([gpu, g2], [d.value, d.value], 8)
+            assert hip.hipMemcpy(d, want.ctypes.data_as(C.c_void_p), want.nbytes, 1) == 0  # host to device
+            iris_amd.allreduce_films([gpu], [d.value], want.size)
+            back = np.zeros_like(want)
+            assert hip.hipMemcpy(back.ctypes.data_as(C.c_void_p), d, want.nbytes, 2) == 0  # device to host
+            assert np.array_equal(bits(back), bits(want))
+        finally:
+            hip.hipFree(d)
+            iris_amd.ffi.load().iris_allreduce_shutdown()
