@@ -29,7 +29,7 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (vector)"
 # command (profiles/r01_s1_configB_summary.txt: TCC_EA0_WRREQ_64B * 64 + other WRREQ * 32 + TCC_EA0_RDREQ * 64;
 # writes are 16-byte-per-lane streaming stores, which the counter reads exactly on gfx950).  It is the
 # per-sample result buffer: 16 B x 2.12e9 samples.
-MEASURED_TRAFFIC_DEFAULT_WORKLOAD = 3.54e10
+MEASURED_TRAFFIC_DEFAULT_WORKLOAD = 2.66e10
 
 
 def algorithmic_flops(st):

@@ -50,6 +50,8 @@ inline FastDiv make_fastdiv(uint32_t d) {
 }
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv fd) { return fd.shift == 0xffffffffu ? n : __umulhi(n, fd.mul) >> fd.shift; }
 
+struct XyzResult { float x, y, z; };
+
 struct Pool {
     float4 *rayo;  // (ox, oy, oz, hero wavelength)
     float4 *rayd;  // (dx, dy, dz, state bits: alive << 31 | bounce)
@@ -65,7 +67,7 @@ struct WfArgs {
     CamDev cam;
     FrameDev fr;
     Pool pool;
-    float4 *results;          // per item: XYZ of the finished path
+    XyzResult *results;       // per item: XYZ of the finished path (12 bytes: the buffer is written once and read once, both HBM-bound)
     uint32_t *queue;          // per workgroup: slots_per_block entries
     uint32_t *blk_cursor;     // per workgroup: next item (multi-kernel mode)
     uint32_t *blk_qn;         // per workgroup: queue length (multi-kernel mode)
@@ -117,7 +119,8 @@ __device__ __forceinline__ SphereStage stage_spheres(const SceneDev &sc, float4 
 }
 
 __device__ __forceinline__ void store_result(const WfArgs &a, uint32_t item, V3 xyz) {
-    a.results[item] = make_float4(xyz.x, xyz.y, xyz.z, 0.0f);
+    XyzResult r = {xyz.x, xyz.y, xyz.z};
+    a.results[item] = r;
 }
 
 __device__ __forceinline__ void flush_counters(const WfArgs &a, const Counters &c) {
@@ -365,6 +368,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     float t = 0.0f;
     bool work_left = true;               // wave-uniform
     uint32_t q_head = 0u, q_count = 0u;  // wave-uniform
+#ifdef IRIS_PHASE_TIMERS  // diagnostic build only: wave-cycles per phase into counters[4..7]
+    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, ph_t = __builtin_readcyclecounter();
+#define IRIS_PHASE(k) do { unsigned long long n_ = __builtin_readcyclecounter(); ph[k] += n_ - ph_t; ph_t = n_; } while (0)
+#else
+#define IRIS_PHASE(k) do { } while (0)
+#endif
     for (;;) {
         // ---- extend: the next ray of the paths that survived the last bounce ----
         {
@@ -387,6 +396,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                 }
             }
         }
+        IRIS_PHASE(0);
         // ---- generate: camera samples, 64 at a time, until a wave's worth of primary hits is queued ----
         while (work_left && q_count < PQ_LOW) {
             const uint32_t k = wave_reserve(true, &bs.cursor);
@@ -436,6 +446,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             q_count += (uint32_t)__popcll(hmask);
             __builtin_amdgcn_wave_barrier();
         }
+        IRIS_PHASE(1);
         // ---- refill: lanes without a path take a queued primary hit ----
         {
             const bool dead = lane_state == LANE_DEAD;
@@ -459,6 +470,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             q_count -= n;
             __builtin_amdgcn_wave_barrier();
         }
+        IRIS_PHASE(2);
         // ---- shade ----
         const bool active = lane_state == LANE_HIT;
         if (__ballot(active) == 0ull) break;  // nothing in flight, nothing queued, nothing left to generate
@@ -471,7 +483,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                 lane_state = LANE_DEAD;
             }
         }
+        IRIS_PHASE(3);
     }
+#ifdef IRIS_PHASE_TIMERS
+    if (lane_id() == 0u)
+        for (int k = 0; k < 4; k++) atomicAdd(&a.counters[4 + k], ph[k]);
+#endif
+#undef IRIS_PHASE
     flush_counters(a, cnt);
 }
 
@@ -529,14 +547,14 @@ __global__ void __launch_bounds__(BLOCK) k_stage_shade(WfArgs a) {
 }
 
 // ---- film resolve: ordered per-pixel sum of the per-sample results ----
-__global__ void __launch_bounds__(BLOCK) k_resolve(const float4 *__restrict__ results, float4 *__restrict__ film_acc, float *__restrict__ out,
+__global__ void __launch_bounds__(BLOCK) k_resolve(const XyzResult *__restrict__ results, float4 *__restrict__ film_acc, float *__restrict__ out,
                                                    uint32_t npix, uint32_t n_samples, int first, int last, float weight) {
     uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
     if (pix >= npix) return;
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (!first) { float4 acc = film_acc[pix]; x = acc.x; y = acc.y; z = acc.z; }
     for (uint32_t s = 0; s < n_samples; s++) {  // tile.rs:159: xyz_sum += ..., ascending sample index
-        float4 r = results[(size_t)s * npix + pix];
+        XyzResult r = results[(size_t)s * npix + pix];
         x += r.x; y += r.y; z += r.z;
     }
     if (last) {  // tile.rs:165: xyz_sum * weight
@@ -674,7 +692,7 @@ struct iris_ctx {
     Pool pool = {};
     uint32_t *d_queue = nullptr, *d_blk_cursor = nullptr, *d_blk_qn = nullptr, *d_live = nullptr;
     unsigned long long *d_counters = nullptr;
-    float4 *d_results = nullptr;
+    XyzResult *d_results = nullptr;
     size_t results_cap = 0;  // items
     float4 *d_film_acc = nullptr;
     size_t film_cap = 0;
@@ -1013,7 +1031,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     const uint32_t npix = p->width * p->height;
     c->stats = iris_stats{};
     // chunking of the sample range so that the per-sample result buffer fits its budget
-    uint64_t max_items = std::min<uint64_t>((uint64_t)c->result_bytes / sizeof(float4), 1ull << 31);
+    uint64_t max_items = std::min<uint64_t>((uint64_t)c->result_bytes / sizeof(XyzResult), 1ull << 31);
     if (max_items < npix) return fail(c, IRIS_E_LIMIT, "result_bytes is smaller than one sample of the film");
     uint32_t spp_per_chunk = (uint32_t)std::min<uint64_t>(max_items / npix, std::max<uint32_t>(p->spp_count, 1u));
     size_t need_items = (size_t)spp_per_chunk * npix;
@@ -1045,7 +1063,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     uint32_t blocks = (uint32_t)(c->n_cus * per_cu);
     uint32_t spb = (uint32_t)c->slots_per_block;
     if (!reg && (rc = ensure_pools(c, blocks, spb))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
 
     const float weight = 1.0f / (float)p->spp_total;  // tile.rs:140
     if (p->spp_count == 0 || p->max_depth == 0) {  // `for bounces in 0..0` never runs: radiance is zero
@@ -1100,6 +1118,15 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     unsigned long long h[4];
     HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
+#ifdef IRIS_PHASE_TIMERS
+    {
+        unsigned long long t[8];
+        (void)hipMemcpy(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost);
+        const double tot = (double)(t[4] + t[5] + t[6] + t[7]);
+        std::fprintf(stderr, "[phase timers] extend %.1f%% generate %.1f%% refill %.1f%% shade %.1f%% (wave-cycles %.3g)\n", 100.0 * t[4] / tot,
+                     100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, tot);
+    }
+#endif
     c->stats.samples = h[0];
     c->stats.bounces = h[1];
     c->stats.rays = h[2];
@@ -1126,7 +1153,7 @@ int iris_ctx_create(int device, iris_ctx **out) {
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
     c->n_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
