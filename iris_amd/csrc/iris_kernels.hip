@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     bool work_left = true;               // wave-uniform
     uint32_t q_head = 0u, q_count = 0u;  // wave-uniform
 #ifdef IRIS_PHASE_TIMERS  // diagnostic build only: wave-cycles per phase into counters[4..7]
-    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, ph_t = __builtin_readcyclecounter();
+    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, ph_t = __builtin_readcyclecounter(), ph_lanes = 0ull, ph_iters = 0ull;
 #define IRIS_PHASE(k) do { unsigned long long n_ = __builtin_readcyclecounter(); ph[k] += n_ - ph_t; ph_t = n_; } while (0)
 #else
 #define IRIS_PHASE(k) do { } while (0)
@@ -474,6 +474,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
         // ---- shade ----
         const bool active = lane_state == LANE_HIT;
         if (__ballot(active) == 0ull) break;  // nothing in flight, nothing queued, nothing left to generate
+#ifdef IRIS_PHASE_TIMERS
+        ph_lanes += (unsigned long long)__popcll(__ballot(active));
+        ph_iters += 1ull;
+#endif
         const bool cont = shade_bounce<INTEG, CLS>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt);
         if (active) {
             if (cont) {
@@ -487,7 +491,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     }
 #ifdef IRIS_PHASE_TIMERS
     if (lane_id() == 0u)
+    {
         for (int k = 0; k < 4; k++) atomicAdd(&a.counters[4 + k], ph[k]);
+        atomicAdd(&a.counters[8], ph_lanes);
+        atomicAdd(&a.counters[9], ph_iters);
+    }
 #endif
 #undef IRIS_PHASE
     flush_counters(a, cnt);
@@ -1063,7 +1071,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     uint32_t blocks = (uint32_t)(c->n_cus * per_cu);
     uint32_t spb = (uint32_t)c->slots_per_block;
     if (!reg && (rc = ensure_pools(c, blocks, spb))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 10 * sizeof(unsigned long long), stream));
 
     const float weight = 1.0f / (float)p->spp_total;  // tile.rs:140
     if (p->spp_count == 0 || p->max_depth == 0) {  // `for bounces in 0..0` never runs: radiance is zero
@@ -1120,11 +1128,12 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     HIP_TRY(c, hipStreamSynchronize(stream));
 #ifdef IRIS_PHASE_TIMERS
     {
-        unsigned long long t[8];
+        unsigned long long t[10];
         (void)hipMemcpy(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost);
         const double tot = (double)(t[4] + t[5] + t[6] + t[7]);
         std::fprintf(stderr, "[phase timers] extend %.1f%% generate %.1f%% refill %.1f%% shade %.1f%% (wave-cycles %.3g)\n", 100.0 * t[4] / tot,
                      100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, tot);
+        std::fprintf(stderr, "[phase timers] shade iterations %llu, lanes holding a hit per iteration %.2f of 64\n", t[9], (double)t[8] / (double)std::max(1ull, t[9]));
     }
 #endif
     c->stats.samples = h[0];
@@ -1153,7 +1162,7 @@ int iris_ctx_create(int device, iris_ctx **out) {
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
     c->n_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_counters, 10 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
