@@ -343,6 +343,31 @@ def test_config_b_full_size_pixels_bit_exact(gpu, iris_trig):
     assert abs(film[60, 960, 1] - 3.0) < 0.1
 
 
+def test_config_c_one_gpu_share_full_size(gpu, iris_trig):
+    """BASELINE config C (3840x2160 at 4096 spp over 8 GPUs): the share of GPU 3 -- sample indices [1536, 2048)
+    of every pixel, 4.25e9 samples, more than 2^31 results, so the result buffer is filled in two pieces -- on
+    this GPU; 48 random pixels are recomputed by the oracle over the same index range; size-independent
+    properties: exact sample count, black sky, and the share of another GPU differs (disjoint streams)."""
+    from iris_amd import Render, Scene
+    scene = Scene.dummy()
+    flat = gpu.upload(scene)
+    w, h, spp, share = 3840, 2160, 4096, 512
+    r = Render(w, h, spp, scene)
+    film = gpu.render_film(r, spp_begin=3 * share, spp_count=share)
+    gs = gpu.stats()
+    assert gs.samples == w * h * share and gs.chunks >= 2
+    assert not np.isnan(film).any() and film[1080, 10].tolist() == [0.0, 0.0, 0.0]
+    osc = iris_trig.OracleScene(flat)
+    ocam = iris_trig.camera_new([0, 0, 0], np.float32(w) / np.float32(h))
+    p = iris_trig.make_params(w, h, spp, spp_begin=3 * share, spp_count=share)
+    rng = np.random.RandomState(4096)
+    for _ in range(48):
+        x, y = int(rng.randint(0, w)), int(rng.randint(h // 3, h))
+        assert np.array_equal(bits(film[y, x]), bits(osc.pixel_xyz(ocam, p, x, y))), (x, y)
+    # a partial film carries share/spp of the light: the emitter's pixel is close to 3.0 / 8
+    assert abs(film[120, 1920, 1] - 3.0 / 8) < 0.02
+
+
 def test_furnace_converges_on_gpu(gpu):
     """Analytic KAT (scene.rs:36-41, README.md:23): Le / (1 - rho) = 0.5."""
     from iris_amd import Render, Scene
