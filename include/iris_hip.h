@@ -186,6 +186,10 @@ const char *iris_last_error(const iris_ctx *ctx);
  *   "bvh_min_prims"   scenes with at least this many spheres get a bounding-volume hierarchy at upload and the
  *                     scans traverse it (default 65; 0 = never: every scan tests every sphere like scene.rs:116-166).
  *                     Closest hit and tie rule are the list scan's; iris_stats.sphere_tests then counts the tests made
+ *   "bvh_leaf"        spheres per leaf of the hierarchy, 1..7 (default 4)
+ *   "x_park_max", "x_fire"  register-resident kernel, scenes with non-Lambertian BSDFs and no environment map: hits on
+ *                     such surfaces are set aside and shaded together; a mixed iteration runs when this many lanes
+ *                     wait with one (default 24) or this many primary ones are queued (default 110)
  *   "specialize"      1 (default): scenes with only Lambertian BSDFs over constant spectra (the reference's
  *                     default scene) run kernels compiled for that class; 0: always the general kernels
  * None of them changes a single bit of the result.

@@ -420,6 +420,7 @@ IRIS_DEV V3 spectral_to_xyz(F4 value, F4 wl) {
 struct SceneDev {
     const float4 *spheres;      // (cx, cy, cz, r), primitive order
     const int2 *prim_info;      // (material_index, light_index), -1 = None
+    const unsigned char *prim_kind;  // 0: Lambertian material or none; 1: any other BSDF (the register kernel sets those hits aside)
     const iris_bsdf *bsdfs;
     const iris_spectrum *spectra;
     const float *spec_over_pi;  // per spectrum: c0 / PI for a constant spectrum (the IEEE quotient, formed once on the host)
@@ -437,8 +438,12 @@ struct SceneDev {
     // (c0, c1, c2, hdr_coefficient) = UpsampledHdrSpectrum; sampling tables built at upload.
     const float4 *env_texels;
     const float *env_func;      // importance x texel solid-angle weight
-    const float *env_cond_cdf;  // env_w + 1 per row
-    const float *env_marg_cdf;  // env_h + 1
+    // The CDFs as the device searches them (EnvSearch below): entries 0 .. n-1 of each CDF row padded to whole
+    // blocks of 32 with a value no draw reaches, plus one coarser level per factor of 32 (every 32nd entry).
+    const float *env_cond_lvl[3];
+    const float *env_marg_lvl[3];
+    uint32_t env_cond_stride[3];  // floats per row at each level (marginal: one row)
+    uint32_t env_cond_levels, env_marg_levels;
     uint32_t env_w, env_h;
     float env_integral;
 };
@@ -877,25 +882,46 @@ IRIS_DEV void env_eval(const SceneDev &sc, V3 d, F4 wl, F4 &le, float &pdf) {
     le = spectrum_evaluate(sp, wl, false);
     pdf = sc.env_integral > 0.0f ? ((sc.env_func[idx] / sc.env_integral) * 0.25f) * jac : 0.0f;
 }
-// Piecewise-constant 1-D distribution: the largest idx with cdf[idx] <= u by bisection ("CDF search"),
-// then the continuous position inside that bin, in [0, 1].
-IRIS_DEV float env_sample_1d(const float *cdf, uint32_t n, float u, uint32_t &idx) {
-    uint32_t lo = 0u, hi = n;
-    while (hi - lo > 1u) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (cdf[mid] <= u) lo = mid; else hi = mid;
+// Piecewise-constant 1-D distribution: the largest idx with cdf[idx] <= u ("CDF search"), then the continuous
+// position inside that bin, in [0, 1].  docs/SPEC.md states the search as a bisection; on the GPU a bisection is
+// ceil(log2 n) DEPENDENT loads per lane (20 L2 round trips for a 1024^2 map, with three waves per SIMD to hide
+// them), so the same index is found 32 entries at a time instead: because the CDF is non-decreasing, the index is
+// the number of entries 1 .. n-1 that are <= u, counted block by block from the coarsest level down -- two rounds of
+// eight independent 16-byte loads for n = 1024.  Same index, hence the same sample, bit for bit (tested against the
+// oracle's bisection).
+#define IRIS_ENV_BLOCK 32u
+#define IRIS_ENV_PAD 2.0f  // pads blocks: above every draw (u < 1)
+IRIS_DEV float env_sample_1d(const float *const lvl[3], const uint32_t stride[3], uint32_t n_levels, uint32_t row, uint32_t n, float u, uint32_t &idx) {
+    uint32_t b = 0u;  // the index found at the level above = the block to search at this level
+    for (uint32_t l = n_levels; l-- > 0u;) {
+        const float4 *p = (const float4 *)(lvl[l] + (size_t)row * stride[l] + (size_t)b * IRIS_ENV_BLOCK);
+        float4 v[IRIS_ENV_BLOCK / 4u];
+#pragma unroll
+        for (uint32_t k = 0; k < IRIS_ENV_BLOCK / 4u; k++) v[k] = p[k];
+        uint32_t count = 0u;  // entry 0 of the block is <= u by the level above (cdf[0] = 0 at the top)
+#pragma unroll
+        for (uint32_t k = 0; k < IRIS_ENV_BLOCK / 4u; k++) {
+            if (k != 0u) count += v[k].x <= u ? 1u : 0u;
+            count += v[k].y <= u ? 1u : 0u;
+            count += v[k].z <= u ? 1u : 0u;
+            count += v[k].w <= u ? 1u : 0u;
+        }
+        b = b * IRIS_ENV_BLOCK + count;
     }
-    float c0 = cdf[lo], c1 = cdf[lo + 1u];
+    const float *cdf = lvl[0] + (size_t)row * stride[0];
+    float c0 = cdf[b];
+    float c1 = b + 1u < n ? cdf[b + 1u] : 1.0f;  // cdf[n] = 1 exactly (iris_envmap_tables)
     float den = c1 - c0;
     float du = u - c0;
     if (den > 0.0f) du = du / den;
-    idx = lo;
-    return ((float)lo + du) / (float)n;
+    idx = b;
+    return ((float)b + du) / (float)n;
 }
 IRIS_DEV V3 env_sample(const SceneDev &sc, float u0, float u1) {
     uint32_t r, c;
-    float vv = env_sample_1d(sc.env_marg_cdf, sc.env_h, u0, r);
-    float uu = env_sample_1d(sc.env_cond_cdf + (size_t)r * (sc.env_w + 1u), sc.env_w, u1, c);
+    const uint32_t marg_stride[3] = {0u, 0u, 0u};
+    float vv = env_sample_1d(sc.env_marg_lvl, marg_stride, sc.env_marg_levels, 0u, sc.env_h, u0, r);
+    float uu = env_sample_1d(sc.env_cond_lvl, sc.env_cond_stride, sc.env_cond_levels, r, sc.env_w, u1, c);
     return normalize(oct_point(2.0f * uu - 1.0f, 2.0f * vv - 1.0f));
 }
 
