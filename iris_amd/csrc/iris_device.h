@@ -528,7 +528,20 @@ struct SphereStage {
     bool resident;         // n_prims <= cap and the window already holds the list
     bool bvh;              // the scene has a hierarchy: the scans traverse it instead of the list
     uint32_t *stack;       // bvh: this lane's traversal stack in LDS, entry k at stack[k * IRIS_BLOCK]
+    // Entries from stack_lds_n on live in global memory (entry k at stack_hi[(k - stack_lds_n) * stack_hi_stride]): the
+    // far child is stacked only when both boxes are hit, so a ray rarely holds more than a few entries, and LDS --
+    // 1 KiB per level and workgroup -- is what limits the resident waves of the latency-bound traversal.
+    uint32_t stack_lds_n;
+    uint32_t *stack_hi;
+    uint32_t stack_hi_stride;
 };
+IRIS_DEV void bvh_push(const SphereStage &st, uint32_t sp, uint32_t ref) {
+    if (sp < st.stack_lds_n) st.stack[sp * IRIS_BLOCK] = ref;
+    else st.stack_hi[(size_t)(sp - st.stack_lds_n) * st.stack_hi_stride] = ref;
+}
+IRIS_DEV uint32_t bvh_pop(const SphereStage &st, uint32_t sp) {
+    return sp < st.stack_lds_n ? st.stack[sp * IRIS_BLOCK] : st.stack_hi[(size_t)(sp - st.stack_lds_n) * st.stack_hi_stride];
+}
 #define IRIS_BVH_STACK 24u   // entries per lane; the host builds no hierarchy deeper than this
 
 // One pass over `n` staged spheres (n real ones, followed by fillers up to a multiple of IRIS_SCAN_PAD),
@@ -581,7 +594,7 @@ IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray,
 // bits.  References come out of the fetch that tested the node's box, so a node's own record is never read
 // again; a stacked reference whose subtree a later hit has made unreachable fails its children's box tests.
 IRIS_DEV uint32_t bvh_ref(float4 lo, float4 hi) { return __float_as_uint(lo.w) | (__float_as_uint(hi.w) << 29); }
-IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests) {
+IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests) {
     const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     uint32_t n_tests = sc.bvh_big_count;
     for (uint32_t k = 0; k < sc.bvh_big_count; k++) bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
@@ -603,13 +616,13 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, f
                 const bool left_first = hl && (!hr || tl <= tr);
                 const uint32_t ref_l = bvh_ref(l0, l1), ref_r = bvh_ref(r0, r1);
                 if (hl && hr) {  // the farther child waits on the stack (depth <= IRIS_BVH_STACK by construction)
-                    stack[sp * IRIS_BLOCK] = left_first ? ref_r : ref_l;
+                    bvh_push(st, sp, left_first ? ref_r : ref_l);
                     sp++;
                 }
                 ref = left_first ? ref_l : ref_r;
             } else if (sp != 0u) {
                 sp--;
-                ref = stack[sp * IRIS_BLOCK];
+                ref = bvh_pop(st, sp);
             } else {
                 have = false;
             }
@@ -620,7 +633,7 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, uint32_t *stack, const Ray &ray, f
         n_tests += count;
         if (sp != 0u) {
             sp--;
-            ref = stack[sp * IRIS_BLOCK];
+            ref = bvh_pop(st, sp);
         } else {
             have = false;
         }
@@ -638,7 +651,7 @@ IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool activ
     int closest = -1;
     float a = len_squared(ray.d);  // sphere.rs:27 (loop-invariant)
     if (st.bvh) {
-        if (active) bvh_closest(sc, st.stack, ray, a, closest_t, closest, tests);
+        if (active) bvh_closest(sc, st, ray, a, closest_t, closest, tests);
     } else if (st.resident) {
         if (active) scan_window<4>(st.lds, sc.n_prims, 0u, ray, a, closest_t, closest);
         if (active) tests += sc.n_prims;

@@ -80,6 +80,8 @@ struct WfArgs {
     uint32_t items_per_block;
     uint32_t slots_per_block;
     uint32_t sphere_cap;      // LDS window, in spheres
+    uint32_t *stack_hi;       // register kernel with a hierarchy: traversal-stack entries beyond the LDS ones, entry-major
+    uint32_t stack_lds_n;     // traversal-stack entries per lane kept in LDS
     uint32_t *xq;             // register kernel, general classes: per wave, PQ_FIELDS x XQ_CAP words (see k_regwave)
     uint32_t x_park_max;      // lanes allowed to wait with a non-Lambertian hit before a mixed iteration is run
     uint32_t x_fire;          // queued non-Lambertian primary hits that trigger a mixed iteration
@@ -113,6 +115,9 @@ __device__ __forceinline__ SphereStage stage_spheres(const SceneDev &sc, float4 
     st.cap = cap;
     st.bvh = sc.n_bvh_nodes != 0u;
     st.stack = (uint32_t *)win + threadIdx.x;  // hierarchy: the window's LDS holds the traversal stacks instead
+    st.stack_lds_n = 0xffffffffu;              // all of them (the register kernel keeps only the first levels there)
+    st.stack_hi = nullptr;
+    st.stack_hi_stride = 0u;
     st.resident = !st.bvh && sc.n_prims <= cap;
     if (st.resident) {
         const uint32_t n_pad = (sc.n_prims + IRIS_SCAN_PAD - 1u) & ~(IRIS_SCAN_PAD - 1u);
@@ -341,7 +346,7 @@ constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz
 template <bool BVH> struct PqGeom { static constexpr uint32_t CAP = BVH ? 80u : 104u; };  // < CAP - 63 queued when a generate phase starts, <= 64 added by it
 
 template <int INTEG, int CLS, bool BVH>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_regwave(WfArgs a) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH && CLS == IRIS_CLS_LAMBERT_CONSTANT ? 4 : 3))) k_regwave(WfArgs a) {
     constexpr uint32_t PQ_CAP = PqGeom<BVH>::CAP;
     constexpr uint32_t PQ_LOW = PQ_CAP - 63u;  // generate while fewer records than this are queued
     extern __shared__ float4 sphere_win[];
@@ -354,6 +359,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     DrawRing ring = ring_lds + threadIdx.x;
     SphereStage st = stage_spheres(a.sc, sphere_win, a.sphere_cap);
     st.bvh = BVH;        // compile-time: the other scan's code is not compiled in
+    if (BVH) {
+        st.stack_lds_n = a.stack_lds_n;
+        st.stack_hi = a.stack_hi + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+        st.stack_hi_stride = gridDim.x * BLOCK;
+    }
     st.resident = !BVH;  // launched only when the whole list is in the window (or with a hierarchy): no barrier inside the scans
     if (threadIdx.x == 0) {
         block_range(a, bs.cursor, bs.w_end);
@@ -759,7 +769,8 @@ struct iris_ctx {
     bool scene_is_lambert_constant = false;
     SceneDev sc = {};
     void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr, *d_spec_over_pi = nullptr, *d_prim_kind = nullptr;
-    uint32_t *d_xq = nullptr;
+    uint32_t *d_xq = nullptr, *d_stack_hi = nullptr;
+    size_t stack_hi_words = 0;
     size_t xq_waves = 0;
     int64_t x_park_max = 24, x_fire = 110;
     void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr;
@@ -1035,6 +1046,7 @@ static_assert(SPHERE_CAP % IRIS_SCAN_PAD == 0, "the LDS window holds whole scan 
 // for short lists (where shading, not the scans, is the cost) and for scenes with a hierarchy; the pool/queue
 // kernels serve long lists scanned sphere by sphere (where compacting rays before every scan pays).
 constexpr uint32_t REGISTER_KERNEL_MAX_PRIMS = 64;
+constexpr uint32_t REG_STACK_LDS = 8;  // traversal-stack entries per lane the register kernel keeps in LDS
 bool use_register_kernel(const iris_ctx *c) {
     if (c->multi_kernel || c->mode == 1) return false;
     if (c->sc.n_bvh_nodes) return true;  // no LDS window needed: the register-resident kernel is the faster one (measured)
@@ -1141,6 +1153,17 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     uint32_t blocks = (uint32_t)(c->n_cus * per_cu);
     uint32_t spb = (uint32_t)c->slots_per_block;
     if (!reg && (rc = ensure_pools(c, blocks, spb))) return rc;
+    const uint32_t reg_stack_lds = std::min<uint32_t>(std::max<uint32_t>(c->bvh_depth, 1u), REG_STACK_LDS);
+    if (reg && c->sc.n_bvh_nodes && c->bvh_depth > reg_stack_lds) {  // deeper stack entries of the register kernel: global memory
+        const size_t words = (size_t)blocks * BLOCK * (c->bvh_depth - reg_stack_lds);
+        if (c->stack_hi_words < words) {
+            dev_free(c->d_stack_hi);
+            c->d_stack_hi = nullptr;
+            c->stack_hi_words = 0;
+            if ((rc = dev_alloc(c, &c->d_stack_hi, words))) return rc;
+            c->stack_hi_words = words;
+        }
+    }
     if (reg && c->scene_class == IRIS_CLS_GENERAL && c->xq_waves < (size_t)blocks * (BLOCK / 64)) {  // second hit queue of the general classes
         dev_free(c->d_xq);
         c->d_xq = nullptr;
@@ -1179,6 +1202,9 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.slots_per_block = spb;
         a.sphere_cap = sphere_cap_for(c);
         a.xq = c->d_xq;
+        a.stack_hi = c->d_stack_hi;
+        a.stack_lds_n = reg_stack_lds;
+        if (reg && c->sc.n_bvh_nodes) a.sphere_cap = reg_stack_lds * BLOCK * sizeof(uint32_t) / sizeof(float4);  // LDS for the first levels only
         a.x_park_max = (uint32_t)c->x_park_max;
         a.x_fire = (uint32_t)c->x_fire;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
@@ -1260,7 +1286,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
-    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq);
+    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
