@@ -147,9 +147,12 @@ def main():
                          "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
                          "traffic": MEASURED_TRAFFIC_DEFAULT_WORKLOAD if default_workload else None,
                          "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / args.steps / max(1, st.chunks), 3),
-                         "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters)"},
+                         "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters = the oracle's: what the "
+                                       "reference's algorithm executes; sky_samples of them are proved black by the sky mask and not traced)",
+                         "achieved_traced_only": round((flops - args.steps * (F_CAM + F_ISECT * len(scene.primitives)) * st.sky_samples) / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms > 0 else 0.0},
             "rays_per_s": round(st.rays / (kernel_ms / args.steps * 1e-3), 1) if kernel_ms else None,
-            "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests, "bvh_depth": st.bvh_depth},
+            "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests, "bvh_depth": st.bvh_depth,
+                                  "sky_samples": st.sky_samples},
         }
         if world == 1 and not args.no_cpu_baseline:
             n_threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))

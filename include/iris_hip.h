@@ -143,6 +143,8 @@ typedef struct {
     uint32_t chunks;       /* sample-range chunks the render was split into */
     uint32_t kernel;       /* which kernel traced the paths: enum iris_kernel_variant */
     uint32_t bvh_depth;    /* levels of the scene's hierarchy (0: none; the scans test every sphere) */
+    uint64_t sky_samples;  /* of `samples`: camera samples of pixels that the sky mask proved black (counted in samples, rays
+                              and sphere_tests as the reference executes them, but not traced) */
 } iris_stats;
 
 enum iris_kernel_variant {
@@ -190,6 +192,9 @@ const char *iris_last_error(const iris_ctx *ctx);
  *   "x_park_max", "x_fire"  register-resident kernel, scenes with non-Lambertian BSDFs and no environment map: hits on
  *                     such surfaces are set aside and shaded together; a mixed iteration runs when this many lanes
  *                     wait with one (default 24) or this many primary ones are queued (default 110)
+ *   "sky_mask"        1 (default): scenes of up to 64 spheres without an environment map: a pre-pass marks the pixels
+ *                     whose camera samples provably hit nothing (conservative cone test in binary64); they are exactly
+ *                     black in the reference and are neither traced nor stored; 0: every sample is traced
  *   "specialize"      1 (default): scenes with only Lambertian BSDFs over constant spectra (the reference's
  *                     default scene) run kernels compiled for that class; 0: always the general kernels
  * None of them changes a single bit of the result.

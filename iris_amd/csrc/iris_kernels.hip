@@ -80,6 +80,8 @@ struct WfArgs {
     uint32_t items_per_block;
     uint32_t slots_per_block;
     uint32_t sphere_cap;      // LDS window, in spheres
+    const unsigned char *sky;  // register kernel, short lists, no environment map: per pixel, 1 = no camera sample of this pixel
+                               // can hit anything (k_sky_mask); nullptr: not used
     uint32_t *stack_hi;       // register kernel with a hierarchy: traversal-stack entries beyond the LDS ones, entry-major
     uint32_t stack_lds_n;     // traversal-stack entries per lane kept in LDS
     uint32_t *xq;             // register kernel, general classes: per wave, PQ_FIELDS x XQ_CAP words (see k_regwave)
@@ -383,6 +385,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
     // (Measured: S3 71.5 -> 67.1 ms.  Under an environment map the light-pick branch and the CDF search dominate the
     // divergence and the scheme costs 4 %, so that class keeps one kind.)
     constexpr bool TWO_KINDS = CLS == IRIS_CLS_GENERAL;
+    // sky mask (k_sky_mask): short lists without an environment map only -- under a map a miss needs its ray
+    const bool USE_SKY = !BVH && CLS != IRIS_CLS_GENERAL_ENV && a.sky != nullptr;
+    uint32_t n_sky = 0u;
     uint32_t *const xq = TWO_KINDS ? a.xq + (size_t)(blockIdx.x * (BLOCK / 64) + threadIdx.x / 64) * PQ_FIELDS * XQ_CAP : nullptr;
     uint32_t x_head = 0u, x_count = 0u;  // wave-uniform
     auto hit_is_x = [&](int prim_) -> bool { return TWO_KINDS && a.sc.prim_kind[prim_] != 0u; };
@@ -433,22 +438,33 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
             work_left = __ballot(k >= w_end) == 0ull;  // the list is handed out in ascending k
             CamSample cs = {};
             Ray ray = {v3(a.cam.px, a.cam.py, a.cam.pz), v3(0.0f, 0.0f, 1.0f)};
-            uint32_t new_item = 0u, sample_index = 0u;
+            uint32_t new_item = 0u, sample_index = 0u, pix = 0u;
+            bool live = valid;  // false for a sample of a pixel that k_sky_mask has marked: it is exactly zero and never stored
             if (valid) {
                 new_item = (uint32_t)id;
                 uint32_t s_local = fast_div(new_item, a.div_npix);
-                uint32_t pix = new_item - s_local * a.npix;
-                uint32_t y = fast_div(pix, a.div_width);
-                uint32_t x = pix - y * a.fr.width;
+                pix = new_item - s_local * a.npix;
                 sample_index = a.s_begin + s_local;
-                cs = camera_sample(a.cam, a.fr, sobol_lds, x, y, sample_index);
-                ray.d = cs.d;
                 cnt.samples++;
+                if (USE_SKY && a.sky[pix] != 0) {  // counted as the reference executes it: one scan over the whole list
+                    live = false;
+                    cnt.rays++;
+                    cnt.sphere_tests += a.sc.n_prims;
+                    n_sky++;
+                }
             }
-            float t_new;
-            int prim_new;
-            scan_closest(a.sc, st, valid, ray, t_new, prim_new, cnt.sphere_tests);
-            if (valid) {
+            float t_new = 0.0f;
+            int prim_new = -1;
+            if (!USE_SKY || __ballot(live) != 0ull) {  // 64 consecutive pixels of a row: mostly all sky or none
+                if (live) {
+                    uint32_t y = fast_div(pix, a.div_width);
+                    uint32_t x = pix - y * a.fr.width;
+                    cs = camera_sample(a.cam, a.fr, sobol_lds, x, y, sample_index);
+                    ray.d = cs.d;
+                }
+                scan_closest(a.sc, st, live, ray, t_new, prim_new, cnt.sphere_tests);
+            }
+            if (live) {
                 cnt.rays++;
                 if (prim_new < 0) {  // `None => break`
                     if (env_on<CLS>(a.sc)) {
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
                     }
                 }
             }
-            const bool hitp = valid && prim_new >= 0;
+            const bool hitp = live && prim_new >= 0;
             const bool hitx = hitp && hit_is_x(prim_new);
             const unsigned long long hmask = __ballot(hitp && !hitx);
             if (hitp && !hitx) {
@@ -576,6 +592,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
 #endif
 #undef IRIS_PHASE
     flush_counters(a, cnt);
+    {
+        unsigned long long x = n_sky;
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane_id() == 0u && x) atomicAdd(&a.counters[10], x);
+    }
 }
 
 // ---- the same two stages as separate kernels (profiling / north-star layout) ----
@@ -631,11 +652,71 @@ __global__ void __launch_bounds__(BLOCK) k_stage_shade(WfArgs a) {
     flush_counters(a, cnt);
 }
 
+// ---- sky mask: pixels none of whose camera samples can hit anything ----
+// A camera sample that hits nothing returns exactly zero when the scene has no environment map (`None => break`,
+// hwss_naive.rs:41-44, with radiance still 0), and a pixel all of whose samples do so is exactly black.  For the
+// reference's default scene that is half of the film, and each of those samples still pays a Sobol set, the
+// camera transform and a scan.  This pass decides per pixel, conservatively and in binary64, whether ANY ray
+// through the pixel's jitter footprint (tile.rs:149-153: clip-space offsets in [0, 0.5/W) x [0, 0.5/H)) can touch
+// any sphere: the footprint is bounded by a cone around its centre ray (half-angle = the largest angle to its four
+// corners), each sphere by its cone of half-angle asin(r / dist), and the pixel is marked only if every pair of
+// cones is separated by more than 2e-3 rad.  The f32 camera ray deviates from the exact one by ~1e-7 rad and the f32
+// discriminant of sphere.rs:30 errs by ~2e-7 dist^2, against a miss margin of >= 4e-6 dist^2 implied by 2e-3 rad,
+// so a marked pixel's samples all miss in the reference's arithmetic as well.  Anything unusual (camera inside or
+// near a sphere, NaN) leaves the pixel unmarked, i.e. on the normal path.  Marked pixels cost nothing in the trace
+// kernel and are written as zeros by the resolve; the work counters count their samples as the reference executes them.
+__global__ void __launch_bounds__(BLOCK) k_sky_mask(CamDev cam, FrameDev fr, const float4 *spheres, uint32_t n_prims, unsigned char *sky) {
+    const uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
+    if (pix >= fr.width * fr.height) return;
+    const uint32_t y = pix / fr.width, x = pix - y * fr.width;
+    // tile.rs:134-138 in the f32 arithmetic of camera_sample (exactly representable in binary64), then the footprint corners
+    const float cxf = (((float)x + 0.5f) / (float)fr.width - 0.5f) * 2.0f;
+    const float cyf = (((float)y + 0.5f) / (float)fr.height - 0.5f) * -2.0f;
+    const double jx = 0.5 / (double)fr.width, jy = 0.5 / (double)fr.height;
+    double dir[5][3];
+    bool ok = true;
+    for (int k = 0; k < 5; k++) {
+        const double tx = (double)cxf + (k == 4 ? 0.5 * jx : ((k & 1) ? jx : 0.0));
+        const double ty = (double)cyf + (k == 4 ? 0.5 * jy : ((k & 2) ? jy : 0.0));
+        const double w = (double)cam.m[12] * tx + (double)cam.m[13] * ty + (double)cam.m[15];
+        double v[3];
+        for (int r = 0; r < 3; r++) v[r] = ((double)cam.m[4 * r] * tx + (double)cam.m[4 * r + 1] * ty + (double)cam.m[4 * r + 3]) / w;
+        v[0] -= (double)cam.px; v[1] -= (double)cam.py; v[2] -= (double)cam.pz;
+        const double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        ok = ok && len > 0.0 && len < 1e30 && w > 0.0;  // NaN fails every comparison
+        for (int r = 0; r < 3; r++) dir[k][r] = v[r] / len;
+    }
+    double beta = 0.0;  // half-angle of the footprint cone around the centre ray dir[4]
+    for (int k = 0; k < 4; k++) {
+        const double c = dir[4][0] * dir[k][0] + dir[4][1] * dir[k][1] + dir[4][2] * dir[k][2];
+        const double ang = acos(c > 1.0 ? 1.0 : c);
+        ok = ok && ang >= 0.0 && ang < 0.2;
+        beta = ang > beta ? ang : beta;
+    }
+    bool all_miss = ok;
+    for (uint32_t i = 0; i < n_prims && all_miss; i++) {
+        const float4 sp = spheres[i];
+        const double vx = (double)sp.x - (double)cam.px, vy = (double)sp.y - (double)cam.py, vz = (double)sp.z - (double)cam.pz;
+        const double dist = sqrt(vx * vx + vy * vy + vz * vz), r = fabs((double)sp.w);
+        const bool outside = dist > r * 1.001 + 1e-6 && dist < 1e30;
+        const double alpha = asin(outside ? r / dist : 1.0);
+        const double c = (dir[4][0] * vx + dir[4][1] * vy + dir[4][2] * vz) / dist;
+        const double theta = acos(c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c));
+        all_miss = outside && theta > alpha + beta + 2e-3;
+    }
+    sky[pix] = all_miss ? 1 : 0;
+}
+
 // ---- film resolve: ordered per-pixel sum of the per-sample results ----
 __global__ void __launch_bounds__(BLOCK) k_resolve(const XyzResult *__restrict__ results, float4 *__restrict__ film_acc, float *__restrict__ out,
-                                                   uint32_t npix, uint32_t n_samples, int first, int last, float weight) {
+                                                   uint32_t npix, uint32_t n_samples, int first, int last, float weight, const unsigned char *__restrict__ sky) {
     uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
     if (pix >= npix) return;
+    if (sky != nullptr && sky[pix] != 0) {  // every sample of the pixel is exactly zero and was never stored: 0 + 0 + ... = 0, 0 * weight = 0
+        if (last) { out[3 * (size_t)pix + 0] = 0.0f; out[3 * (size_t)pix + 1] = 0.0f; out[3 * (size_t)pix + 2] = 0.0f; }
+        else film_acc[pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (!first) { float4 acc = film_acc[pix]; x = acc.x; y = acc.y; z = acc.z; }
     for (uint32_t s = 0; s < n_samples; s++) {  // tile.rs:159: xyz_sum += ..., ascending sample index
@@ -770,6 +851,9 @@ struct iris_ctx {
     SceneDev sc = {};
     void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr, *d_spec_over_pi = nullptr, *d_prim_kind = nullptr;
     uint32_t *d_xq = nullptr, *d_stack_hi = nullptr;
+    unsigned char *d_sky = nullptr;
+    size_t sky_cap = 0;
+    int64_t sky_mask = 1;
     size_t stack_hi_words = 0;
     size_t xq_waves = 0;
     int64_t x_park_max = 24, x_fire = 110;
@@ -1171,7 +1255,20 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         if ((rc = dev_alloc(c, &c->d_xq, (size_t)blocks * (BLOCK / 64) * PQ_FIELDS * XQ_CAP))) return rc;
         c->xq_waves = (size_t)blocks * (BLOCK / 64);
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 10 * sizeof(unsigned long long), stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), stream));
+    // sky mask: register kernel on a short list without an environment map
+    const bool use_sky = c->sky_mask && reg && !c->sc.n_bvh_nodes && c->sc.env_w == 0u && p->spp_count != 0u && p->max_depth != 0u;
+    if (use_sky) {
+        if (c->sky_cap < npix) {
+            dev_free(c->d_sky);
+            c->d_sky = nullptr;
+            c->sky_cap = 0;
+            if ((rc = dev_alloc(c, &c->d_sky, (size_t)npix))) return rc;
+            c->sky_cap = npix;
+        }
+        hipLaunchKernelGGL(k_sky_mask, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, cam_dev(cam), frame_dev(p), c->sc.spheres, c->sc.n_prims, c->d_sky);
+        HIP_TRY(c, hipGetLastError());
+    }
 
     const float weight = 1.0f / (float)p->spp_total;  // tile.rs:140
     if (p->spp_count == 0 || p->max_depth == 0) {  // `for bounces in 0..0` never runs: radiance is zero
@@ -1202,6 +1299,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.slots_per_block = spb;
         a.sphere_cap = sphere_cap_for(c);
         a.xq = c->d_xq;
+        a.sky = use_sky ? c->d_sky : nullptr;
         a.stack_hi = c->d_stack_hi;
         a.stack_lds_n = reg_stack_lds;
         if (reg && c->sc.n_bvh_nodes) a.sphere_cap = reg_stack_lds * BLOCK * sizeof(uint32_t) / sizeof(float4);  // LDS for the first levels only
@@ -1218,7 +1316,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         HIP_TRY(c, hipEventRecord(c->ev1, stream));
         bool first = done == 0, last = done + n_s >= p->spp_count;
         hipLaunchKernelGGL(k_resolve, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, c->d_results, c->d_film_acc, d_out, npix, n_s,
-                           first ? 1 : 0, last ? 1 : 0, weight);
+                           first ? 1 : 0, last ? 1 : 0, weight, (const unsigned char *)(use_sky ? c->d_sky : nullptr));
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev2, stream));
         HIP_TRY(c, hipEventSynchronize(c->ev2));
@@ -1229,7 +1327,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         resolve_ms += ms;
         c->stats.chunks += 1;
     }
-    unsigned long long h[4];
+    unsigned long long h[12];
     HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
 #ifdef IRIS_PHASE_TIMERS
@@ -1249,6 +1347,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     c->stats.kernel_ms = trace_ms;
     c->stats.resolve_ms = resolve_ms;
     c->stats.bvh_depth = c->bvh_depth;
+    c->stats.sky_samples = h[10];
     c->stats.kernel = reg ? IRIS_KERNEL_REGISTER : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED);
     return IRIS_OK;
 }
@@ -1268,7 +1367,7 @@ int iris_ctx_create(int device, iris_ctx **out) {
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
     c->n_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&c->d_counters, 10 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_counters, 12 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
@@ -1286,7 +1385,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
-    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi);
+    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_sky);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1322,6 +1421,8 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "x_fire") {
         if (value < 1 || value > 129) return fail(c, IRIS_E_ARG, "x_fire out of range [1, 129]");
         c->x_fire = value;
+    } else if (k == "sky_mask") {
+        c->sky_mask = value ? 1 : 0;
     } else if (k == "bvh_leaf") {
         if (value < 1 || value > 7) return fail(c, IRIS_E_ARG, "bvh_leaf out of range [1, 7]");
         c->bvh_leaf = value;  // takes effect at the next iris_scene_upload

@@ -67,7 +67,7 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("bounces", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("kernel_ms", C.c_double), ("resolve_ms", C.c_double), ("launches", C.c_uint32), ("chunks", C.c_uint32),
-                ("kernel", C.c_uint32), ("bvh_depth", C.c_uint32)]
+                ("kernel", C.c_uint32), ("bvh_depth", C.c_uint32), ("sky_samples", C.c_uint64)]
 
 
 KERNEL_NAMES = ("k_wavefront", "k_stage_gen_extend+k_stage_shade", "k_regwave")
