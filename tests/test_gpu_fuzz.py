@@ -99,3 +99,44 @@ def test_random_scene_film_bit_exact(gpu, oracle, seed):
     finally:
         oracle.set_trig_mode(oracle.TRIG_LIBM)
         table.close()
+
+
+def test_sky_mask_never_changes_a_bit(gpu):
+    """The sky mask (k_sky_mask) only skips samples that are exactly zero: films and work counters with and
+    without it are identical, on scenes chosen to sit on its margins -- spheres a fraction of a pixel wide,
+    spheres grazing pixel footprints at full resolution, the camera near, inside and far from spheres, cameras away
+    from the origin -- and it does find the sky of the default scene."""
+    import iris_amd
+    from iris_amd import Camera, ConstantSpectrum, LambertianBsdf, Render, Scene, Sphere
+    rng = np.random.RandomState(77)
+    cases = []
+    s1 = Scene.dummy()
+    cases.append((s1, Render(1920, 1080, 1, s1)))
+    cases.append((s1, Render(333, 77, 3, s1, camera=Camera((0.3, 0.4, -1.0), np.float32(333) / np.float32(77)))))
+    cases.append((s1, Render(64, 64, 4, s1, camera=Camera((0.0, -0.2, 3.0), np.float32(1.0)))))      # inside the middle sphere
+    cases.append((s1, Render(64, 64, 4, s1, camera=Camera((0.0, -0.2, 1.9995), np.float32(1.0)))))   # half a millimetre off its surface
+    for k in range(6):
+        s = Scene()
+        s.add_emissive_material(Sphere((0.0, 50.0, 10.0), 5.0), LambertianBsdf(ConstantSpectrum(0.5)), ConstantSpectrum(40.0))
+        for _ in range(40):
+            z = float(rng.uniform(2.0, 400.0))
+            r = float(np.float32(z * rng.uniform(0.0002, 0.004)))  # 0.1 .. 2 pixels wide at 512 pixels across a 90 degree view
+            s.add_material(Sphere((float(np.float32(rng.uniform(-0.9, 0.9) * z)), float(np.float32(rng.uniform(-0.9, 0.9) * z)), float(np.float32(z))), r),
+                           LambertianBsdf(ConstantSpectrum(0.7)))
+        cases.append((s, Render(512, 512, 2, s)))
+    with iris_amd.HipWavefront(0, sky_mask=0) as plain:
+        for i, (scene, r) in enumerate(cases):
+            gpu.upload(scene)
+            plain.upload(scene)
+            a, sa = gpu.render_film(r), gpu.stats()
+            b, sb = plain.render_film(r), plain.stats()
+            assert np.array_equal(bits(a), bits(b)), i
+            assert (sa.samples, sa.bounces, sa.rays, sa.sphere_tests) == (sb.samples, sb.bounces, sb.rays, sb.sphere_tests), i
+            assert sb.sky_samples == 0
+            if i == 0:
+                assert 0.45 < sa.sky_samples / sa.samples < 0.60
+            if i == 2:
+                assert sa.sky_samples == 0  # the camera is inside a sphere: nothing can be proved
+            if i >= 4:
+                assert sa.sky_samples / sa.samples > 0.9  # nearly everything is sky; the specks are still found
+                assert (a[..., 1] > 0).sum() > 20
