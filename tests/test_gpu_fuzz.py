@@ -66,7 +66,7 @@ def random_scene(rng, table, n_spheres, with_env):
     return s
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IRIS_FUZZ_SEEDS", "48"))))  # IRIS_FUZZ_SEEDS=1000 for a soak
 def test_random_scene_film_bit_exact(gpu, oracle, seed):
     import iris_amd
     from iris_amd import Render, UpsampleTable
