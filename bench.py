@@ -81,9 +81,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    # Rehearsal on a one-GPU box only: IRIS_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and the film exchange on
+    # gloo (RCCL refuses two ranks on one GPU).  The driver's multi-GPU runs never set it.
+    share = os.environ.get("IRIS_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[args.scene[:2]]()
     if args.scene.endswith("env"):  # procedural HDR sky through the RGB -> spectrum table (a data fixture; tools/rgb2spec_opt.c makes it)

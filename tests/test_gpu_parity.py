@@ -545,3 +545,29 @@ def test_multi_gpu_entry_points_on_one_gpu(gpu, iris_trig):
         finally:
             hip.hipFree(d)
             iris_amd.ffi.load().iris_allreduce_shutdown()
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's multi-rank code path (rendezvous, sample split, film all-reduce, max-over-ranks timing, one JSON
+    line from rank 0) with two ranks sharing this GPU and gloo standing in for RCCL (which refuses two ranks on
+    one device).  The driver's real multi-GPU runs use one GPU per rank and the nccl backend."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IRIS_BENCH_SHARE_DEVICE="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--width", "320", "--height", "180", "--spp", "8"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["counters_per_step"]["samples"] == 320 * 180 * 8  # rank 0's share: 8 of the 16 spp
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
