@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
     bool work_left = true;               // wave-uniform
     uint32_t q_head = 0u, q_count = 0u;  // wave-uniform
 #ifdef IRIS_PHASE_TIMERS  // diagnostic build only: wave-cycles per phase into counters[4..7]
-    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, ph_t = __builtin_readcyclecounter(), ph_lanes = 0ull, ph_iters = 0ull;
+    unsigned long long ph[4] = {0ull, 0ull, 0ull, 0ull}, ph_t = __builtin_readcyclecounter(), ph_lanes = 0ull, ph_iters = 0ull, ph_mixed = 0ull, ph_mixed_lanes = 0ull, ph_mixed_x = 0ull, ph_kind[4] = {0ull, 0ull, 0ull, 0ull};
 #define IRIS_PHASE(k) do { unsigned long long n_ = __builtin_readcyclecounter(); ph[k] += n_ - ph_t; ph_t = n_; } while (0)
 #else
 #define IRIS_PHASE(k) do { } while (0)
@@ -570,6 +570,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
 #ifdef IRIS_PHASE_TIMERS
         ph_lanes += (unsigned long long)__popcll(__ballot(active));
         ph_iters += 1ull;
+        if (mixed) {
+            int kd = -1;
+            if (lane_state == LANE_HITX && prim >= 0) { const int m_ = a.sc.prim_info[prim].x; kd = m_ >= 0 ? (int)a.sc.bsdfs[m_].kind : -1; }
+            for (int kk = 1; kk <= 3; kk++) ph_kind[kk] += (unsigned long long)__popcll(__ballot(kd == kk));
+            ph_mixed += 1ull; ph_mixed_lanes += (unsigned long long)__popcll(__ballot(active)); ph_mixed_x += (unsigned long long)__popcll(__ballot(lane_state == LANE_HITX)); }
 #endif
         const bool cont = shade_bounce<INTEG, CLS>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt);
         if (active) {
@@ -588,6 +593,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
         for (int k = 0; k < 4; k++) atomicAdd(&a.counters[4 + k], ph[k]);
         atomicAdd(&a.counters[8], ph_lanes);
         atomicAdd(&a.counters[9], ph_iters);
+        atomicAdd(&a.counters[11], ph_mixed);
+        atomicAdd(&a.counters[12], ph_mixed_lanes);
+        atomicAdd(&a.counters[13], ph_mixed_x);
+        for (int kk = 1; kk <= 3; kk++) atomicAdd(&a.counters[13 + kk], ph_kind[kk]);
     }
 #endif
 #undef IRIS_PHASE
@@ -1255,7 +1264,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         if ((rc = dev_alloc(c, &c->d_xq, (size_t)blocks * (BLOCK / 64) * PQ_FIELDS * XQ_CAP))) return rc;
         c->xq_waves = (size_t)blocks * (BLOCK / 64);
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 12 * sizeof(unsigned long long), stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 17 * sizeof(unsigned long long), stream));
     // sky mask: register kernel on a short list without an environment map
     const bool use_sky = c->sky_mask && reg && !c->sc.n_bvh_nodes && c->sc.env_w == 0u && p->spp_count != 0u && p->max_depth != 0u;
     if (use_sky) {
@@ -1327,17 +1336,21 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         resolve_ms += ms;
         c->stats.chunks += 1;
     }
-    unsigned long long h[12];
+    unsigned long long h[17];
     HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
 #ifdef IRIS_PHASE_TIMERS
     {
-        unsigned long long t[10];
+        unsigned long long t[17];
         (void)hipMemcpy(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost);
         const double tot = (double)(t[4] + t[5] + t[6] + t[7]);
         std::fprintf(stderr, "[phase timers] extend %.1f%% generate %.1f%% refill %.1f%% shade %.1f%% (wave-cycles %.3g)\n", 100.0 * t[4] / tot,
                      100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, tot);
         std::fprintf(stderr, "[phase timers] shade iterations %llu, lanes holding a hit per iteration %.2f of 64\n", t[9], (double)t[8] / (double)std::max(1ull, t[9]));
+        std::fprintf(stderr, "[phase timers] mixed iterations %llu: %.2f lanes shaded, %.2f of them of the second kind\n", t[11],
+                     (double)t[12] / (double)std::max(1ull, t[11]), (double)t[13] / (double)std::max(1ull, t[11]));
+        std::fprintf(stderr, "[phase timers] second-kind lanes per mixed iteration: microfacet %.2f specular %.2f fresnel %.2f\n", (double)t[14] / (double)std::max(1ull, t[11]),
+                     (double)t[15] / (double)std::max(1ull, t[11]), (double)t[16] / (double)std::max(1ull, t[11]));
     }
 #endif
     c->stats.samples = h[0];
@@ -1367,7 +1380,7 @@ int iris_ctx_create(int device, iris_ctx **out) {
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
     c->n_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&c->d_counters, 12 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_counters, 17 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
