@@ -325,3 +325,49 @@ def test_env_upload_errors(gpu):
         gpu.upload(Scene.dummy())
         assert np.array_equal(bits(plain), bits(gpu.render_film(iris_amd.Render(16, 16, 4, Scene.dummy()))))
         assert lit[0, 0, 1] > 0.9 and plain[0, 0, 1] == 0.0  # the corner pixel sees the sky
+
+
+# ---------------------------------------------------------------------------------------------- host helpers (CPU)
+
+def test_envmap_host_helpers(table):
+    """iris_envmap_from_latlong, iris_envmap_texels_from_rgb, iris_envmap_tables argument checks (no GPU)."""
+    import iris_amd
+    from iris_amd import EnvMap
+    L = iris_amd.ffi.load()
+    fp = C.POINTER(C.c_float)
+    # a constant lat-long image stays constant
+    src = np.full((16, 32, 3), 0.25, np.float32)
+    oct_ = EnvMap.latlong_to_oct(src, 24, 24)
+    assert oct_.shape == (24, 24, 3) and np.allclose(oct_, 0.25, atol=1e-6)
+    # upper half bright, lower half dark: octahedral texels follow the sign of the texel direction's y
+    src = np.zeros((64, 128, 3), np.float32)
+    src[:32] = 1.0
+    oct_ = EnvMap.latlong_to_oct(src, 32, 32)
+    dirs = EnvMap.texel_directions(32, 32)
+    up = dirs[..., 1] > 0.1
+    down = dirs[..., 1] < -0.1
+    assert np.all(oct_[up][:, 0] > 0.9) and np.all(oct_[down][:, 0] < 0.1)
+    # one bright lat-long texel towards +x lands in the octahedral texel whose direction is +x
+    src = np.zeros((64, 128, 3), np.float32)
+    src[32, 96] = 100.0  # theta = pi/2 (+0.5 texel), phi = 3pi/2 -> atan2(dx, -dz) = 3pi/2: dx = -1?  checked below by direction
+    oct_ = EnvMap.latlong_to_oct(src, 64, 64)
+    r, c = np.unravel_index(np.argmax(oct_[..., 0]), oct_.shape[:2])
+    d = EnvMap.texel_directions(64, 64)[r, c]
+    phi = 2 * np.pi * (96 + 0.5) / 128
+    expect = np.array([np.sin(phi), 0.0, -np.cos(phi)])  # phi = atan2(dx, -dz), theta ~ pi/2
+    assert np.dot(d, expect) > 0.99
+    # texels_from_rgb == get_spectrum_hdr per texel, with the clamp as a parameter
+    rgb = np.array([[0.2, 0.5, 0.1], [3.0, 80.0, 1.0], [0.0, 0.0, 0.0]], np.float32)
+    for max_hdr in (50.0, float("inf")):
+        tex = np.zeros((3, 4), np.float32)
+        imp = np.zeros(3, np.float32)
+        assert L.iris_envmap_texels_from_rgb(table.handle, rgb.ctypes.data_as(fp), 3, C.c_float(max_hdr), tex.ctypes.data_as(fp), imp.ctypes.data_as(fp)) == 0
+        for i in range(3):
+            ref = table.get_spectrum_hdr(rgb[i])
+            assert np.array_equal(bits(tex[i, :3]), bits(ref.coefficients))
+            assert tex[i, 3] == (min(ref.hdr_coefficient, 50.0) if max_hdr == 50.0 else max(rgb[i].max(), 1.0))
+        assert np.allclose(imp, rgb @ np.array([0.2126, 0.7152, 0.0722], np.float32), rtol=1e-6)
+    # argument checks
+    assert L.iris_envmap_tables(None, None, None, None, None) != 0
+    assert L.iris_envmap_from_latlong(None, 1, 1, 1, 1, None) != 0
+    assert L.iris_envmap_texels_from_rgb(None, None, 0, C.c_float(1.0), None, None) != 0
