@@ -243,6 +243,13 @@ int iris_envmap_from_latlong(const float *rgb, uint32_t width, uint32_t height, 
 int iris_envmap_texels_from_rgb(const iris_upsample_table *table, const float *rgb, size_t n_texels, float max_hdr,
                                 float *texels, float *importance);
 
+/* Radiance RGBE picture (.hdr) -> linear RGB f32, rows top to bottom: the file format of the environment maps the
+ * reference's authors keep beside the code (`.hdr` files under data/, .gitignore:7; its own reader is a README.md:36 TODO).
+ * Call with rgb == NULL to get the size, then with a buffer of width*height*3 floats (rgb_floats = its length).
+ * Reads plain, old and adaptive run-length scanlines in the standard "-Y h +X w" orientation.
+ * IRIS_E_ARG: cannot open, not an RGBE picture, or damaged; IRIS_E_LIMIT: buffer too small. */
+int iris_hdr_read(const char *path, uint32_t *width, uint32_t *height, float *rgb, size_t rgb_floats);
+
 /* ---- the hot path ----------------------------------------------------- */
 
 /* Renders sample indices [spp_begin, spp_begin+spp_count) of every pixel and

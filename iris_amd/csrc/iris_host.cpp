@@ -355,3 +355,121 @@ int iris_envmap_texels_from_rgb(const iris_upsample_table *t, const float *rgb, 
 }
 
 }  // extern "C"
+
+// ---- Radiance RGBE pictures (.hdr): the format of the environment maps the reference's authors keep beside the ----
+// ---- code (`data/*.hdr`, .gitignore:7; README.md:36 "Own PNG / HDR code" is still a TODO there)                ----
+// Header lines up to an empty one ("#?RADIANCE" / "#?RGBE" first, FORMAT=32-bit_rle_rgbe), a resolution line
+// "-Y h +X w" (the standard orientation: rows top to bottom, columns left to right; others are refused), then per
+// scanline either the adaptive run-length form (2, 2, w_hi, w_lo, then the four channels one after the other as
+// runs (count > 128: count - 128 copies of the next byte) and literals), the old run-length form (a pixel
+// (1, 1, 1, n) repeats the previous pixel n << shift times) or plain pixels.  A pixel (r, g, b, e) is
+// (m + 0.5) * 2^(e - 136) per channel, zero when e is 0 (Radiance's colr_color).
+namespace {
+struct HdrFile {
+    FILE *f = nullptr;
+    ~HdrFile() { if (f) std::fclose(f); }
+};
+bool hdr_header(FILE *f, uint32_t *w, uint32_t *h) {
+    char line[512];
+    if (!std::fgets(line, sizeof line, f)) return false;
+    if (std::strncmp(line, "#?RADIANCE", 10) != 0 && std::strncmp(line, "#?RGBE", 6) != 0) return false;
+    bool format_ok = false;
+    for (;;) {
+        if (!std::fgets(line, sizeof line, f)) return false;
+        if (line[0] == '\n' || (line[0] == '\r' && line[1] == '\n')) break;
+        if (std::strncmp(line, "FORMAT=", 7) == 0) {
+            if (std::strncmp(line + 7, "32-bit_rle_rgbe", 15) != 0) return false;  // XYZE pictures are another colour space
+            format_ok = true;
+        }
+    }
+    if (!format_ok) return false;
+    if (!std::fgets(line, sizeof line, f)) return false;
+    unsigned long hh = 0, ww = 0;
+    if (std::sscanf(line, "-Y %lu +X %lu", &hh, &ww) != 2) return false;
+    if (hh == 0 || ww == 0 || hh > 65536 || ww > 65536) return false;
+    *w = (uint32_t)ww;
+    *h = (uint32_t)hh;
+    return true;
+}
+bool hdr_scanline(FILE *f, uint32_t w, std::vector<unsigned char> &px /* 4 * w */) {
+    unsigned char head[4];
+    if (std::fread(head, 1, 4, f) != 4) return false;
+    if (w >= 8 && w < 32768 && head[0] == 2 && head[1] == 2 && (head[2] & 0x80) == 0) {  // adaptive run-length form
+        if ((((uint32_t)head[2]) << 8 | head[3]) != w) return false;
+        for (int ch = 0; ch < 4; ch++) {
+            uint32_t x = 0;
+            while (x < w) {
+                int n = std::fgetc(f);
+                if (n == EOF) return false;
+                if (n > 128) {
+                    n -= 128;
+                    const int v = std::fgetc(f);
+                    if (v == EOF || x + (uint32_t)n > w) return false;
+                    for (int k = 0; k < n; k++) px[4 * (x++) + ch] = (unsigned char)v;
+                } else {
+                    if (n == 0 || x + (uint32_t)n > w) return false;
+                    for (int k = 0; k < n; k++) {
+                        const int v = std::fgetc(f);
+                        if (v == EOF) return false;
+                        px[4 * (x++) + ch] = (unsigned char)v;
+                    }
+                }
+            }
+        }
+        return true;
+    }
+    // plain pixels, possibly with old-style repeats
+    uint32_t x = 0;
+    int shift = 0;
+    unsigned char p[4] = {head[0], head[1], head[2], head[3]};
+    bool have = true;
+    while (x < w) {
+        if (!have && std::fread(p, 1, 4, f) != 4) return false;
+        have = false;
+        if (p[0] == 1 && p[1] == 1 && p[2] == 1) {
+            if (x == 0 || shift > 24) return false;
+            const uint64_t n = (uint64_t)p[3] << shift;
+            if (x + n > w) return false;
+            for (uint64_t k = 0; k < n; k++, x++) std::memcpy(&px[4 * x], &px[4 * (x - 1)], 4);
+            shift += 8;
+        } else {
+            std::memcpy(&px[4 * x], p, 4);
+            x++;
+            shift = 0;
+        }
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int iris_hdr_read(const char *path, uint32_t *width, uint32_t *height, float *rgb, size_t rgb_floats) {
+    if (!path || !width || !height) return IRIS_E_ARG;
+    HdrFile file;
+    file.f = std::fopen(path, "rb");
+    if (!file.f) return IRIS_E_ARG;
+    uint32_t w = 0, h = 0;
+    if (!hdr_header(file.f, &w, &h)) return IRIS_E_ARG;
+    *width = w;
+    *height = h;
+    if (!rgb) return IRIS_OK;  // size query
+    if (rgb_floats < (size_t)w * h * 3) return IRIS_E_LIMIT;
+    std::vector<unsigned char> px((size_t)4 * w);
+    for (uint32_t y = 0; y < h; y++) {
+        if (!hdr_scanline(file.f, w, px)) return IRIS_E_ARG;
+        float *row = rgb + (size_t)y * w * 3;
+        for (uint32_t x = 0; x < w; x++) {
+            const unsigned char *p = &px[4 * (size_t)x];
+            if (p[3] == 0) {
+                row[3 * x] = row[3 * x + 1] = row[3 * x + 2] = 0.0f;
+            } else {
+                const float scale = std::ldexp(1.0f, (int)p[3] - 136);
+                for (int k = 0; k < 3; k++) row[3 * x + k] = ((float)p[k] + 0.5f) * scale;
+            }
+        }
+    }
+    return IRIS_OK;
+}
+
+}  // extern "C"

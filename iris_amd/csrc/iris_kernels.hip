@@ -894,8 +894,8 @@ struct Bvh {
     std::vector<uint32_t> prim;
     uint32_t depth = 0;
     uint32_t n_big = 0;  // the last n_big leaf-ordered spheres are outside the tree
+    uint32_t leaf = 4;   // spheres per leaf, <= 7: a node reference keeps the count in three bits, the first sphere in 29 (option bvh_leaf)
 };
-uint32_t BVH_LEAF = 4;  // <= 7: a node reference keeps the count in three bits, the first sphere in 29 (option bvh_leaf)
 float4 with_bits(float x, float y, float z, uint32_t w) {
     float f;
     std::memcpy(&f, &w, 4);
@@ -930,7 +930,7 @@ void build_bvh_node(const iris_sphere *sp, std::vector<uint32_t> &order, uint32_
     const float pad = 1e-3f * mag;
     const float lo[3] = {box.lo[0] - pad, box.lo[1] - pad, box.lo[2] - pad}, hi[3] = {box.hi[0] + pad, box.hi[1] + pad, box.hi[2] + pad};
     out.depth = std::max(out.depth, depth);
-    if (end - begin <= BVH_LEAF) {
+    if (end - begin <= out.leaf) {
         std::sort(order.begin() + begin, order.begin() + end);  // leaf: spheres in ascending primitive order
         out.nodes[2 * node] = with_bits(lo[0], lo[1], lo[2], begin);
         out.nodes[2 * node + 1] = with_bits(hi[0], hi[1], hi[2], end - begin);
@@ -1002,7 +1002,7 @@ void build_bvh_node(const iris_sphere *sp, std::vector<uint32_t> &order, uint32_
 constexpr uint32_t BVH_MAX_BIG = 16;
 // false: no hierarchy (non-finite geometry, nothing left for a tree) -- the list scan is used instead
 bool build_bvh(const iris_sphere *sp, uint32_t n, uint32_t leaf, Bvh &out) {
-    BVH_LEAF = leaf;
+    out.leaf = leaf;
     BvhBounds cen;
     for (uint32_t i = 0; i < n; i++) {
         if (!std::isfinite(sp[i].cx) || !std::isfinite(sp[i].cy) || !std::isfinite(sp[i].cz) || !std::isfinite(sp[i].r)) return false;

@@ -20,7 +20,7 @@ EXPORTS = (
     "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_film_to_rgb",
     "iris_get_stats", "iris_allreduce_films", "iris_allreduce_shutdown", "iris_render_multi", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
     "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_envmap_tables", "iris_oct_to_dir", "iris_dir_to_oct",
-    "iris_envmap_from_latlong", "iris_envmap_texels_from_rgb", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
+    "iris_envmap_from_latlong", "iris_envmap_texels_from_rgb", "iris_hdr_read", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
 )
 
 
@@ -119,6 +119,7 @@ def load():
         "iris_dir_to_oct": (None, [fp, fp]),
         "iris_envmap_from_latlong": (C.c_int, [fp, u32, u32, u32, u32, fp]),
         "iris_envmap_texels_from_rgb": (C.c_int, [vp, fp, C.c_size_t, C.c_float, fp, fp]),
+        "iris_hdr_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), fp, C.c_size_t]),
         "iris_dbg_sampler": (C.c_int, [vp, u32, u32p, u32, u32, fp]),
         "iris_dbg_raygen": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(RenderParams), u32, u32p, fp, fp, fp]),
         "iris_dbg_intersect": (C.c_int, [vp, u32, fp, fp, i32p, fp]),

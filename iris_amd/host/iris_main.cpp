@@ -5,7 +5,7 @@
 //   iris_render [--width W] [--height H] [--spp N] [--scene dummy|furnace|spheres10k|glossy]
 //               [--integrator hwss_naive|hwss_slow|swss_naive|swss_slow] [--max-depth D] [--min-depth D]
 //               [--gpus G] [--device I] [--share-device] [--out out.exr|out.pfm] [--dump-scene]
-//               [--env none|white|sky] [--env-size N] [--table srgb.coeff]
+//               [--env none|white|sky|FILE.hdr] [--env-size N] [--table srgb.coeff]
 //
 // What it mirrors: WIDTH/HEIGHT/TOTAL_SPP and CurrentIntegrator (main.rs:27-31) become flags; the
 // thread pool popping tiles (main.rs:87-107) becomes one host thread per GPU, each rendering the
@@ -105,7 +105,7 @@ int usage(const char *argv0) {
                  "usage: %s [--width W] [--height H] [--spp N] [--scene dummy|furnace|spheres10k|glossy]\n"
                  "          [--integrator hwss_naive|hwss_slow|swss_naive|swss_slow] [--max-depth D] [--min-depth D]\n"
                  "          [--gpus G] [--device I] [--share-device] [--out FILE.exr|FILE.pfm] [--dump-scene]\n"
-                 "          [--env none|white|sky] [--env-size N] [--table FILE.coeff]\n", argv0);
+                 "          [--env none|white|sky|FILE.hdr] [--env-size N] [--table FILE.coeff]\n", argv0);
     return 2;
 }
 
@@ -162,6 +162,25 @@ int main(int argc, char **argv) {
             return 1;
         }
         scene.env_map = iris_host::EnvMap::sky(table, env_size, env_size);
+        iris_upsample_table_free(table);
+    } else if (ends_with(env_name, ".hdr")) {  // an equirectangular Radiance picture (data/*.hdr, .gitignore:7)
+        uint32_t w = 0, h = 0;
+        if (iris_hdr_read(env_name.c_str(), &w, &h, nullptr, 0) != IRIS_OK) {
+            std::fprintf(stderr, "cannot read %s as an RGBE picture\n", env_name.c_str());
+            return 1;
+        }
+        std::vector<float> latlong((size_t)w * h * 3), oct((size_t)env_size * env_size * 3);
+        iris_upsample_table *table = nullptr;
+        if (env_size == 0 || iris_hdr_read(env_name.c_str(), &w, &h, latlong.data(), latlong.size()) != IRIS_OK ||
+            iris_envmap_from_latlong(latlong.data(), w, h, env_size, env_size, oct.data()) != IRIS_OK) {
+            std::fprintf(stderr, "%s is damaged\n", env_name.c_str());
+            return 1;
+        }
+        if (iris_upsample_table_load(table_path.c_str(), &table) != IRIS_OK) {
+            std::fprintf(stderr, "--env FILE.hdr needs an RGB->spectrum table: cannot load %s (tools/rgb2spec_opt.c makes one)\n", table_path.c_str());
+            return 1;
+        }
+        scene.env_map = iris_host::EnvMap::from_rgb(table, oct, env_size, env_size);
         iris_upsample_table_free(table);
     } else if (env_name != "none") return usage(argv[0]);
     iris_host::Scene::Flat flat = scene.flatten();

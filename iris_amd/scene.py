@@ -144,6 +144,26 @@ class EnvMap:
         return out
 
     @staticmethod
+    def read_hdr(path):
+        """Radiance RGBE picture (.hdr) -> (H, W, 3) linear RGB f32 (iris_hdr_read)."""
+        L = ffi.load()
+        w, h = C.c_uint32(), C.c_uint32()
+        rc = L.iris_hdr_read(str(path).encode(), C.byref(w), C.byref(h), None, 0)
+        if rc != ffi.IRIS_OK:
+            raise ffi.IrisError("iris_hdr_read: cannot read %s as an RGBE picture (%d)" % (path, rc))
+        out = np.zeros((h.value, w.value, 3), np.float32)
+        rc = L.iris_hdr_read(str(path).encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+        if rc != ffi.IRIS_OK:
+            raise ffi.IrisError("iris_hdr_read: %s is damaged (%d)" % (path, rc))
+        return out
+
+    @classmethod
+    def from_hdr(cls, path, table, width=1024, height=1024, max_hdr=float("inf")):
+        """An equirectangular .hdr picture (row 0 = +y pole) as an environment map: read, resample to the octahedral
+        layout, upsample per texel."""
+        return cls.from_rgb(cls.latlong_to_oct(cls.read_hdr(path), width, height), table, max_hdr)
+
+    @staticmethod
     def texel_directions(width, height):
         """(H, W, 3) unit directions of the texel centres (iris_oct_to_dir)."""
         L = ffi.load()

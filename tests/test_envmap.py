@@ -371,3 +371,121 @@ def test_envmap_host_helpers(table):
     assert L.iris_envmap_tables(None, None, None, None, None) != 0
     assert L.iris_envmap_from_latlong(None, 1, 1, 1, 1, None) != 0
     assert L.iris_envmap_texels_from_rgb(None, None, 0, C.c_float(1.0), None, None) != 0
+
+
+# ---- Radiance RGBE pictures (.hdr) ---------------------------------------------------------------------
+
+def _rgbe_header(w, h, magic=b"#?RADIANCE"):
+    return magic + b"\n# written by tests/test_envmap.py\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n" + ("-Y %d +X %d\n" % (h, w)).encode()
+
+
+def _rle_channel(row):
+    """Adaptive run-length form of one channel of one scanline (runs of >= 3 equal bytes, literals otherwise)."""
+    out, i, n = bytearray(), 0, len(row)
+    while i < n:
+        run = 1
+        while i + run < n and run < 127 and row[i + run] == row[i]:
+            run += 1
+        if run >= 3:
+            out += bytes([128 + run, row[i]])
+            i += run
+            continue
+        j = i
+        while j < n and j - i < 128:
+            r = 1
+            while j + r < n and r < 3 and row[j + r] == row[j]:
+                r += 1
+            if r >= 3:
+                break
+            j += 1
+        out += bytes([j - i]) + bytes(row[i:j])
+        i = j
+    return bytes(out)
+
+
+def _rgbe_expected(px):
+    """Radiance's colr_color: (m + 0.5) * 2^(e - 136), zero when e == 0."""
+    e = px[..., 3].astype(np.int32)
+    scale = np.where(e == 0, 0.0, np.ldexp(1.0, e - 136)).astype(np.float32)
+    return ((px[..., :3].astype(np.float32) + np.float32(0.5)) * scale[..., None]).astype(np.float32) * (e != 0)[..., None]
+
+
+def test_hdr_reader_all_scanline_forms(tmp_path):
+    """iris_hdr_read against the published RGBE definition: plain pixels, the adaptive run-length form (runs and
+    literals, every channel), the old repeat-marker form, a zero exponent, both magic lines; damaged and
+    unsupported files are refused, not misread."""
+    from iris_amd import EnvMap
+    from iris_amd.ffi import IrisError
+    rng = np.random.RandomState(11)
+    w, h = 37, 9
+    px = rng.randint(0, 256, (h, w, 4)).astype(np.uint8)
+    px[..., 3] = rng.randint(118, 140, (h, w))
+    px[2, 5:30] = px[2, 5]          # a long run in every channel
+    px[3, :, 3] = 128               # constant exponent: the common case in real pictures
+    px[4, 7] = (9, 9, 9, 0)         # zero exponent = black
+    px[px[..., 0] == 1, 0] = 2      # (1, 1, 1, n) is the old form's repeat marker: keep it out of the plain data
+    want = _rgbe_expected(px)
+
+    flat = tmp_path / "flat.hdr"
+    flat.write_bytes(_rgbe_header(w, h) + px.tobytes())
+    assert np.array_equal(bits(EnvMap.read_hdr(flat)), bits(want))
+
+    rle = tmp_path / "rle.hdr"
+    body = b"".join(bytes([2, 2, w >> 8, w & 255]) + b"".join(_rle_channel(px[y, :, ch]) for ch in range(4)) for y in range(h))
+    rle.write_bytes(_rgbe_header(w, h, b"#?RGBE") + body)
+    assert len(body) < px.nbytes + 4 * h * 5
+    assert np.array_equal(bits(EnvMap.read_hdr(rle)), bits(want))
+
+    old = tmp_path / "old.hdr"   # pixels 1..301 equal: pixel 1, then 300 repeats as two markers, 44 << 0 and 1 << 8
+    w2 = 320
+    row = np.zeros((w2, 4), np.uint8)
+    row[:] = (90, 80, 70, 127)
+    row[0] = (10, 20, 30, 130)
+    row[1:302] = (50, 60, 70, 129)
+    data = bytes(row[0]) + bytes(row[1]) + bytes([1, 1, 1, 44]) + bytes([1, 1, 1, 1]) + b"".join(bytes(row[k]) for k in range(302, w2))
+    old.write_bytes(_rgbe_header(w2, 1) + data)
+    assert np.array_equal(bits(EnvMap.read_hdr(old)), bits(_rgbe_expected(row[None])))
+
+    for name, blob in (("trunc.hdr", _rgbe_header(w, h) + px.tobytes()[:-5]),
+                       ("xyze.hdr", _rgbe_header(w, h).replace(b"rle_rgbe", b"rle_xyze") + px.tobytes()),
+                       ("flip.hdr", _rgbe_header(w, h).replace(b"-Y", b"+Y") + px.tobytes()),
+                       ("magic.hdr", b"P6\n" + px.tobytes()),
+                       ("overrun.hdr", _rgbe_header(w, h) + bytes([2, 2, 0, w]) + bytes([128 + 127, 7]) * 4)):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        with pytest.raises(IrisError):
+            EnvMap.read_hdr(p)
+    with pytest.raises(IrisError):
+        EnvMap.read_hdr(tmp_path / "missing.hdr")
+
+
+def test_hdr_picture_becomes_an_environment_map(tmp_path, table):
+    """An equirectangular .hdr picture through the whole host chain (read -> octahedral resample -> per-texel
+    get_spectrum_hdr -> sampling tables): a bright patch near +x in the picture is where the sampling CDF puts
+    its mass, and the C++ driver accepts the same file."""
+    import subprocess
+    from iris_amd import EnvMap
+    w, h = 64, 32
+    px = np.zeros((h, w, 4), np.uint8)
+    px[:] = (128, 128, 128, 126)                      # grey, 0.125
+    px[h // 2 - 2:h // 2 + 2, 3 * w // 4 - 2:3 * w // 4 + 2] = (200, 180, 120, 136)   # a patch on the equator, three quarters of the way round
+    path = tmp_path / "patch.hdr"
+    path.write_bytes(_rgbe_header(w, h) + px.tobytes())
+    rgb = EnvMap.read_hdr(path)
+    assert rgb.shape == (h, w, 3) and rgb.max() > 150 and abs(rgb[0, 0, 0] - 128.5 / 1024) < 1e-7
+    env = EnvMap.from_hdr(path, table, 48, 48)
+    func = env.tables()[0]
+    dirs = EnvMap.texel_directions(48, 48)
+    peak = dirs[np.unravel_index(np.argmax(func), func.shape)]
+    # iris_envmap_from_latlong: column 0 = direction -z, turning towards +x; the patch sits on the equator 3/4 of the way round
+    phi = 2 * np.pi * 0.75
+    want = np.array([np.sin(phi), 0.0, -np.cos(phi)])
+    assert np.dot(peak, want) > 0.95, (peak, want)
+    assert func.max() > 500 * np.median(func)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "iris_amd", "host", "iris_render")
+    if os.path.exists(exe):  # the CLI stops at the missing GPU, after it has read the picture and built the map
+        r = subprocess.run([exe, "--env", str(path), "--env-size", "16", "--table", TABLE, "--dump-scene"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "env " in r.stdout or "env_map" in r.stdout, r.stdout[-300:]
+        r = subprocess.run([exe, "--env", str(tmp_path / "nope.hdr"), "--dump-scene"], capture_output=True, text=True)
+        assert r.returncode != 0 and "RGBE" in r.stderr
