@@ -81,11 +81,15 @@ def test_random_scene_film_bit_exact(gpu, oracle, seed):
     oracle.set_trig_mode(oracle.TRIG_IRIS)
     try:
         flat = gpu.upload(scene)
-        r = Render(w, h, spp, scene, integrator=integrator, max_depth=max_depth, seed=int(rng.randint(0, 2**31)))
+        render_seed = int(rng.randint(0, 2**31))
+        # half of the scenes are seen from somewhere else than the origin (camera.rs:10-21 takes a position)
+        pos = [float(np.float32(v)) for v in rng.uniform(-3.0, 3.0, 3)] if rng.rand() < 0.5 else [0.0, 0.0, 0.0]
+        r = Render(w, h, spp, scene, integrator=integrator, max_depth=max_depth, seed=render_seed,
+                   camera=iris_amd.Camera(tuple(pos), np.float32(w) / np.float32(h)))
         film = gpu.render_film(r)
         gs = gpu.stats()
         osc = oracle.OracleScene(flat)
-        cam = oracle.camera_new([0, 0, 0], np.float32(w) / np.float32(h))
+        cam = oracle.camera_new(pos, np.float32(w) / np.float32(h))
         want, _, _, st = osc.render(cam, oracle.make_params(w, h, spp, integrator=integrator, max_depth=max_depth, seed=r.seed), nthreads=8)
         same = bits(film) == bits(want)
         both_nan = np.isnan(film) & np.isnan(want)  # NaN payloads may differ; being NaN must not
