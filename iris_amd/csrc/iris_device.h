@@ -595,10 +595,7 @@ IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray,
 // again; a stacked reference whose subtree a later hit has made unreachable fails its children's box tests.
 IRIS_DEV uint32_t bvh_ref(float4 lo, float4 hi) { return __float_as_uint(lo.w) | (__float_as_uint(hi.w) << 29); }
 IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests) {
-    // Box tests only decide which spheres are visited, and the boxes are inflated by 1e-3 of the scene scale: a
-    // reciprocal that is good to an ulp (v_rcp_f32) culls exactly as conservatively as a correctly rounded one and
-    // costs one instruction instead of twelve.  (Zero components give +-inf as the division would.)
-    const V3 inv = v3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+    const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     uint32_t n_tests = sc.bvh_big_count;
     for (uint32_t k = 0; k < sc.bvh_big_count; k++) bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
     const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
