@@ -85,6 +85,8 @@ struct WfArgs {
     uint32_t *stack_hi;       // register kernel with a hierarchy: traversal-stack entries beyond the LDS ones, entry-major
     uint32_t stack_lds_n;     // traversal-stack entries per lane kept in LDS
     uint32_t *xq;             // register kernel, general classes: per wave, PQ_FIELDS x XQ_CAP words (see k_regwave)
+    uint32_t *work_cursor;    // register kernel: next unclaimed item of the launch (one counter in global memory, zeroed per launch)
+    uint32_t work_run;        // register kernel: items a wave claims at a time (a multiple of 64)
     uint32_t x_park_max;      // lanes allowed to wait with a non-Lambertian hit before a mixed iteration is run
     uint32_t x_fire;          // queued non-Lambertian primary hits that trigger a mixed iteration
 };
@@ -355,7 +357,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
     __shared__ uint2 sobol_tab[BVH ? 1 : IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ uint32_t primq[BLOCK / 64][PQ_FIELDS][PQ_CAP];
-    __shared__ BlockShared bs;
     if (!BVH) stage_tables(sobol_tab);
     const SobolLds sobol_lds = BVH ? nullptr : sobol_tab;
     DrawRing ring = ring_lds + threadIdx.x;
@@ -367,12 +368,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
         st.stack_hi_stride = gridDim.x * BLOCK;
     }
     st.resident = !BVH;  // launched only when the whole list is in the window (or with a hierarchy): no barrier inside the scans
-    if (threadIdx.x == 0) {
-        block_range(a, bs.cursor, bs.w_end);
-        bs.qn = 0u;
-    }
     __syncthreads();
-    const uint32_t w_end = bs.w_end;
+    // Work distribution: a wave claims `work_run` consecutive items at a time from one counter in global memory (one
+    // atomic per run, by one lane), so the waves of the whole chip run dry within one run of each other whatever
+    // the pixels cost -- no workgroup is dealt a share in advance.  Which wave traces an item changes nothing: every
+    // result is a function of the item and goes to the item's own slot.
+    uint32_t w_next = 0u, w_lim = 0u;  // wave-uniform: the unclaimed rest of this wave's current run
     uint32_t(*q)[PQ_CAP] = primq[threadIdx.x / 64];
     // General scene classes: hits are of two kinds, Lambertian surfaces (cheap, the bulk) and the rest (GGX,
     // dielectric, mirror: several times the code).  A wave that shades both in the same iteration runs ALL of
@@ -432,10 +433,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
         IRIS_PHASE(0);
         // ---- generate: camera samples, 64 at a time, until a wave's worth of primary hits is queued ----
         while (work_left && q_count < PQ_LOW && (!TWO_KINDS || x_count <= XQ_CAP - 64u)) {
-            const uint32_t k = wave_reserve(true, &bs.cursor);
-            const unsigned long long id = item_of(a, k);
-            const bool valid = k < w_end && id < a.n_items;
-            work_left = __ballot(k >= w_end) == 0ull;  // the list is handed out in ascending k
+            if (w_next >= w_lim) {
+                uint32_t start = 0u;
+                if (lane_id() == 0u) start = atomicAdd(a.work_cursor, a.work_run);
+                start = __builtin_amdgcn_readfirstlane(start);
+                if (start >= a.n_items) { work_left = false; break; }  // overshoot is bounded: every wave asks once too often
+                w_next = start;
+                w_lim = min(start + a.work_run, a.n_items);
+            }
+            const uint32_t id = w_next + lane_id();
+            const bool valid = id < w_lim;
+            w_next += 64u;
             CamSample cs = {};
             Ray ray = {v3(a.cam.px, a.cam.py, a.cam.pz), v3(0.0f, 0.0f, 1.0f)};
             uint32_t new_item = 0u, sample_index = 0u, pix = 0u;
@@ -849,7 +857,8 @@ struct iris_ctx {
     int64_t result_bytes = 64ll << 30;
     int64_t multi_kernel = 0;
     int64_t mode = 0;             // 0 auto, 1 pool/queue kernels, 2 register-resident kernel
-    int64_t reg_blocks_per_cu = 32;  // register-resident kernel: more workgroups than fit, for a short tail
+    int64_t reg_blocks_per_cu = 8;   // register-resident kernel: at least as many workgroups as a CU can hold (8 waves per SIMD);
+                                     // items are claimed from one global counter, so workgroups beyond the resident ones find nothing left
     int64_t bvh_min_prims = 65;   // build a hierarchy for scenes with at least this many spheres (0: never)
     int64_t bvh_leaf = 4;         // spheres per leaf of the hierarchy (1..7)
     int64_t specialize = 1;       // 1: use the kernel compiled for the scene's class; 0: always the general kernel
@@ -862,6 +871,7 @@ struct iris_ctx {
     uint32_t *d_xq = nullptr, *d_stack_hi = nullptr;
     unsigned char *d_sky = nullptr;
     size_t sky_cap = 0;
+    uint32_t *d_work_cursor = nullptr;  // register kernel: the launch's item counter
     int64_t sky_mask = 1;
     size_t stack_hi_words = 0;
     size_t xq_waves = 0;
@@ -1312,6 +1322,10 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.stack_hi = c->d_stack_hi;
         a.stack_lds_n = reg_stack_lds;
         if (reg && c->sc.n_bvh_nodes) a.sphere_cap = reg_stack_lds * BLOCK * sizeof(uint32_t) / sizeof(float4);  // LDS for the first levels only
+        a.work_cursor = c->d_work_cursor;
+        // a run: 2048 items, less for small launches so that every wave still gets several (the tail is one run per wave)
+        a.work_run = std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
+        if (reg) HIP_TRY(c, hipMemsetAsync(c->d_work_cursor, 0, sizeof(uint32_t), stream));
         a.x_park_max = (uint32_t)c->x_park_max;
         a.x_fire = (uint32_t)c->x_fire;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
@@ -1381,7 +1395,7 @@ int iris_ctx_create(int device, iris_ctx **out) {
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
     c->n_cus = prop.multiProcessorCount;
     if (hipMalloc((void **)&c->d_counters, 17 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&c->d_work_cursor, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
         iris_ctx_destroy(c);
@@ -1398,7 +1412,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
-    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_sky);
+    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_sky); dev_free(c->d_work_cursor);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
