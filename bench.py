@@ -26,11 +26,12 @@ sys.path.insert(0, ROOT)
 F_CAM, F_ISECT, F_FRAME, F_SHADE = 120.0, 27.0, 44.0, 400.0
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (vector)"
 # HBM bytes per launch of the path-tracing kernel on the default workload, from the PMC passes of the same
-# command (profiles/r01e_s1_summary.txt: TCC_EA0_WRREQ_64B * 64 + other WRREQ * 32 + TCC_EA0_RDREQ * 64 =
-# 1.914e8 * 64 + 0.8e6 * 32 + 2.3e6 * 64; the writes are 12-byte-per-lane streaming stores, which the counter
+# command (profiles/r01f_s1_summary.txt: TCC_EA0_WRREQ_64B * 64 + other WRREQ * 32 + TCC_EA0_RDREQ * 64 =
+# 1.915e8 * 64 + 1.7e6 * 32 + 1.31e7 * 64; the writes are 12-byte-per-lane streaming stores, which the counter
 # reads exactly on gfx950).  It is the per-sample result buffer: 12 B x the 1.009e9 samples that are traced
-# and stored (the other 1.114e9 belong to pixels the sky mask proves black) = 1.21e10 algorithmic.
-MEASURED_TRAFFIC_DEFAULT_WORKLOAD = 1.24e10
+# and stored (the other 1.114e9 belong to pixels the sky mask proves black) = 1.21e10 algorithmic, plus 0.8e9 read
+# (sky-mask bytes and scene tables that fall out of L2).
+MEASURED_TRAFFIC_DEFAULT_WORKLOAD = 1.31e10
 
 
 def algorithmic_flops(st):

@@ -184,6 +184,7 @@ const char *iris_last_error(const iris_ctx *ctx);
  *                     with a hierarchy, pool/queue kernels for longer lists scanned sphere by sphere);
  *                     1: pool/queue kernels (path state in HBM/L2, rays compacted before every scan);
  *                     2: register-resident kernel (needs the sphere list to fit the LDS window, or a hierarchy)
+ *   "work_run"          register-resident kernel: items a wave claims at a time from the launch's counter (0 = auto, default)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 8: at least what a CU holds; items are claimed from one global counter)
  *   "bvh_min_prims"   scenes with at least this many spheres get a bounding-volume hierarchy at upload and the
  *                     scans traverse it (default 65; 0 = never: every scan tests every sphere like scene.rs:116-166).

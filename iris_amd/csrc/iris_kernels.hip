@@ -872,6 +872,7 @@ struct iris_ctx {
     unsigned char *d_sky = nullptr;
     size_t sky_cap = 0;
     uint32_t *d_work_cursor = nullptr;  // register kernel: the launch's item counter
+    int64_t work_run = 0;               // items per claim (0: chosen per launch)
     int64_t sky_mask = 1;
     size_t stack_hi_words = 0;
     size_t xq_waves = 0;
@@ -1324,7 +1325,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         if (reg && c->sc.n_bvh_nodes) a.sphere_cap = reg_stack_lds * BLOCK * sizeof(uint32_t) / sizeof(float4);  // LDS for the first levels only
         a.work_cursor = c->d_work_cursor;
         // a run: 2048 items, less for small launches so that every wave still gets several (the tail is one run per wave)
-        a.work_run = std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
+        a.work_run = c->work_run ? (uint32_t)c->work_run : std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
         if (reg) HIP_TRY(c, hipMemsetAsync(c->d_work_cursor, 0, sizeof(uint32_t), stream));
         a.x_park_max = (uint32_t)c->x_park_max;
         a.x_fire = (uint32_t)c->x_fire;
@@ -1457,6 +1458,9 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
         c->specialize = value ? 1 : 0;
         if (c->scene_class != IRIS_CLS_GENERAL_ENV)
             c->scene_class = (c->specialize && c->scene_is_lambert_constant) ? IRIS_CLS_LAMBERT_CONSTANT : IRIS_CLS_GENERAL;
+    } else if (k == "work_run") {
+        if (value < 0 || value > (1 << 20) || value % 64) return fail(c, IRIS_E_ARG, "work_run must be 0 (auto) or a multiple of 64 up to 2^20");
+        c->work_run = value;
     } else if (k == "reg_blocks_per_cu") {
         if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "reg_blocks_per_cu out of range [1, 1024]");
         c->reg_blocks_per_cu = value;
