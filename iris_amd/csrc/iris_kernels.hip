@@ -85,7 +85,7 @@ struct WfArgs {
     uint32_t *stack_hi;       // register kernel with a hierarchy: traversal-stack entries beyond the LDS ones, entry-major
     uint32_t stack_lds_n;     // traversal-stack entries per lane kept in LDS
     uint32_t *xq;             // register kernel, general classes: per wave, PQ_FIELDS x XQ_CAP words (see k_regwave)
-    uint32_t *work_cursor;    // register kernel: next unclaimed item of the launch (one counter in global memory, zeroed per launch)
+    unsigned long long *work_cursor;  // register kernel: next unclaimed item of the launch (one counter in global memory, zeroed per launch)
     uint32_t work_run;        // register kernel: items a wave claims at a time (a multiple of 64)
     uint32_t x_park_max;      // lanes allowed to wait with a non-Lambertian hit before a mixed iteration is run
     uint32_t x_fire;          // queued non-Lambertian primary hits that trigger a mixed iteration
@@ -434,10 +434,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
         // ---- generate: camera samples, 64 at a time, until a wave's worth of primary hits is queued ----
         while (work_left && q_count < PQ_LOW && (!TWO_KINDS || x_count <= XQ_CAP - 64u)) {
             if (w_next >= w_lim) {
-                uint32_t start = 0u;
-                if (lane_id() == 0u) start = atomicAdd(a.work_cursor, a.work_run);
-                start = __builtin_amdgcn_readfirstlane(start);
-                if (start >= a.n_items) { work_left = false; break; }  // overshoot is bounded: every wave asks once too often
+                unsigned long long claim = 0ull;  // 64 bits: every wave asks once too often, and grids and runs can be made large
+                if (lane_id() == 0u) claim = atomicAdd(a.work_cursor, (unsigned long long)a.work_run);
+                const uint32_t start = __builtin_amdgcn_readfirstlane((uint32_t)claim);
+                if (__builtin_amdgcn_readfirstlane((uint32_t)(claim >> 32)) != 0u || start >= a.n_items) { work_left = false; break; }
                 w_next = start;
                 w_lim = min(start + a.work_run, a.n_items);
             }
@@ -871,7 +871,7 @@ struct iris_ctx {
     uint32_t *d_xq = nullptr, *d_stack_hi = nullptr;
     unsigned char *d_sky = nullptr;
     size_t sky_cap = 0;
-    uint32_t *d_work_cursor = nullptr;  // register kernel: the launch's item counter
+    unsigned long long *d_work_cursor = nullptr;  // register kernel: the launch's item counter
     int64_t work_run = 0;               // items per claim (0: chosen per launch)
     int64_t sky_mask = 1;
     size_t stack_hi_words = 0;
@@ -1326,7 +1326,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.work_cursor = c->d_work_cursor;
         // a run: 2048 items, less for small launches so that every wave still gets several (the tail is one run per wave)
         a.work_run = c->work_run ? (uint32_t)c->work_run : std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
-        if (reg) HIP_TRY(c, hipMemsetAsync(c->d_work_cursor, 0, sizeof(uint32_t), stream));
+        if (reg) HIP_TRY(c, hipMemsetAsync(c->d_work_cursor, 0, sizeof(unsigned long long), stream));
         a.x_park_max = (uint32_t)c->x_park_max;
         a.x_fire = (uint32_t)c->x_fire;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
@@ -1396,7 +1396,7 @@ int iris_ctx_create(int device, iris_ctx **out) {
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
     c->n_cus = prop.multiProcessorCount;
     if (hipMalloc((void **)&c->d_counters, 17 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&c->d_work_cursor, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&c->d_work_cursor, sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
         iris_ctx_destroy(c);

@@ -266,7 +266,7 @@ def test_sample_ranges_and_schedules_do_not_change_the_film(gpu, iris_trig):
     for opts in ({"result_bytes": 1 << 20}, {"multi_kernel": 1}, {"mode": 1, "blocks_per_cu": 1, "slots_per_block": 256},
                  {"mode": 1, "blocks_per_cu": 8, "slots_per_block": 2048}, {"mode": 1}, {"mode": 2}, {"mode": 1, "specialize": 0}, {"mode": 2, "specialize": 0},
                  {"mode": 2, "reg_blocks_per_cu": 1}, {"mode": 2, "reg_blocks_per_cu": 100},
-                 {"work_run": 64}, {"work_run": 192}, {"work_run": 1 << 20}):  # items per claim from the launch's counter; 2^20 > the whole render
+                 {"work_run": 64}, {"work_run": 192}, {"work_run": 1 << 20}, {"reg_blocks_per_cu": 100, "work_run": 1 << 20}):  # items per claim from the launch's counter; 2^20 > the whole render
         with iris_amd.HipWavefront(0, **opts) as g2:
             g2.upload(scene)
             film = g2.render_film(r)
