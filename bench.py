@@ -94,6 +94,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # communicator set-up and the first collective's one-off costs stay out of the timed steps even with --warmup 0
+        dist.all_reduce(torch.zeros(1, device="cuda"))
+        torch.cuda.synchronize()
 
     scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[args.scene[:2]]()
     if args.scene.endswith("env"):  # procedural HDR sky through the RGB -> spectrum table (a data fixture; tools/rgb2spec_opt.c makes it)
