@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 # Algorithmic flop model (DESIGN.md "Roofline"): FMA = 2, sqrt/div/sin/cos = 1.
 F_CAM, F_ISECT, F_FRAME, F_SHADE = 120.0, 27.0, 44.0, 400.0
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (vector)"
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md, HBM3E bandwidth
 # HBM bytes per launch of the path-tracing kernel on the default workload, from the PMC passes of the same
 # command (profiles/r01f_s1_summary.txt: TCC_EA0_WRREQ_64B * 64 + other WRREQ * 32 + TCC_EA0_RDREQ * 64 =
 # 1.915e8 * 64 + 1.7e6 * 32 + 1.31e7 * 64; the writes are 12-byte-per-lane streaming stores, which the counter
@@ -129,10 +130,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     kernel_ms, flops, st = 0.0, 0.0, None
+    resolve_ms, resolve_bytes = 0.0, 0.0
     for _ in range(args.steps):
         step()
         st = gpu.stats()
         kernel_ms += st.kernel_ms
+        resolve_ms += st.resolve_ms
+        resolve_bytes += 12.0 * (st.samples - st.sky_samples) + 13.0 * args.width * args.height
         flops += algorithmic_flops(st)
     fence()
     elapsed = time.perf_counter() - t0
@@ -164,6 +168,12 @@ def main():
                          "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters = the oracle's: what the "
                                        "reference's algorithm executes; sky_samples of them are proved black by the sky mask and not traced)",
                          "achieved_traced_only": round((flops - args.steps * (F_CAM + F_ISECT * len(scene.primitives)) * st.sky_samples) / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms > 0 else 0.0},
+            # the second kernel of a step, HBM-bound: it reads the 12-byte result of every stored sample once and writes the film
+            "roofline_resolve": {"bound": "hbm", "achieved": round(resolve_bytes / (resolve_ms * 1e-3) / 1e9, 1) if resolve_ms > 0 else 0.0,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(resolve_bytes / (resolve_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if resolve_ms > 0 else 0.0,
+                                 "traffic": None, "kernel": "k_resolve", "kernel_ms_per_step": round(resolve_ms / args.steps, 3),
+                                 "bytes_model": "12 B x stored samples (samples - sky_samples) read + 12 B x pixels written + 1 B x pixels of the sky mask"},
             "rays_per_s": round(st.rays / (kernel_ms / args.steps * 1e-3), 1) if kernel_ms else None,
             "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests, "bvh_depth": st.bvh_depth,
                                   "sky_samples": st.sky_samples},

@@ -736,6 +736,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const XyzResult *__restrict__
     }
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (!first) { float4 acc = film_acc[pix]; x = acc.x; y = acc.y; z = acc.z; }
+#pragma unroll 8
     for (uint32_t s = 0; s < n_samples; s++) {  // tile.rs:159: xyz_sum += ..., ascending sample index
         XyzResult r = results[(size_t)s * npix + pix];
         x += r.x; y += r.y; z += r.z;
