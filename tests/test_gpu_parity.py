@@ -506,6 +506,25 @@ def test_cpp_host_driver_film_equals_python_path(gpu, tmp_path):
                     os.path.join(GOLD, "srgb_res16.coeff"), "--scene", "glossy", "--max-depth", "32", "--out", pfm], check=True, capture_output=True)
     img4 = np.frombuffer(open(pfm, "rb").read(), np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
     assert np.isfinite(img4).all() and img4[0, 0].min() > 0.1  # the sky is visible in the corner
+    # a Radiance .hdr picture as the map: the C++ chain (iris_hdr_read -> iris_envmap_from_latlong -> texels) and the
+    # Python one (EnvMap.from_hdr) are the same library calls, so the films agree bit for bit
+    from iris_amd import UpsampleTable
+    rng = np.random.RandomState(5)
+    px = rng.randint(1, 256, (16, 32, 4)).astype(np.uint8)
+    px[..., 3] = rng.randint(124, 134, (16, 32))
+    px[px[..., 0] == 1, 0] = 2  # (1, 1, 1, n) would be a repeat marker
+    hdr = tmp_path / "map.hdr"
+    hdr.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 16 +X 32\n" + px.tobytes())
+    table = UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff"))
+    s_hdr = Scene.dummy()
+    s_hdr.env_map = EnvMap.from_hdr(hdr, table, 24, 24)
+    table.close()
+    gpu.upload(s_hdr)
+    want_hdr = film_to_rgb(gpu.render_film(Render(80, 48, 6, s_hdr)))
+    subprocess.run([cli, "--width", "80", "--height", "48", "--spp", "6", "--env", str(hdr), "--env-size", "24", "--table",
+                    os.path.join(GOLD, "srgb_res16.coeff"), "--out", pfm], check=True, capture_output=True)
+    img5 = np.frombuffer(open(pfm, "rb").read(), np.float32, 80 * 48 * 3, len(head)).reshape(48, 80, 3)[::-1]
+    assert np.array_equal(bits(img5), bits(want_hdr))
 
 
 def test_multi_gpu_entry_points_on_one_gpu(gpu, iris_trig):
