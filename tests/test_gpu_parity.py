@@ -277,6 +277,11 @@ def test_sample_ranges_and_schedules_do_not_change_the_film(gpu, iris_trig):
     wantp, _ = oracle_film(iris_trig, flat, 96, 64, 16, spp_begin=5, spp_count=4)
     assert np.array_equal(bits(part), bits(wantp))
     assert not gpu.render_film(r, spp_begin=3, spp_count=0).any()
+    # sample indices beyond 2^16 (the Sobol tables hold 16 index bits; higher bits still enter through the index shuffle)
+    rbig = Render(96, 64, 70_003, scene)
+    big = gpu.render_film(rbig, spp_begin=70_000, spp_count=3)
+    wantb, _ = oracle_film(iris_trig, flat, 96, 64, 70_003, spp_begin=70_000, spp_count=3)
+    assert np.array_equal(bits(big), bits(wantb)) and big.any()
 
 
 def test_film_vs_libm_trig_oracle(gpu, libm_trig):
