@@ -594,10 +594,30 @@ IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray,
 // bits.  References come out of the fetch that tested the node's box, so a node's own record is never read
 // again; a stacked reference whose subtree a later hit has made unreachable fails its children's box tests.
 IRIS_DEV uint32_t bvh_ref(float4 lo, float4 hi) { return __float_as_uint(lo.w) | (__float_as_uint(hi.w) << 29); }
+// ANY = false: the closest hit (closest_t = inf, closest = -1 on entry).
+// ANY = true: is there a hit with 0 < t <= closest_t?  (closest_t = the limit on entry and unchanged on return; closest =
+// the index of one such sphere, or -1.)  The limit culls boxes like a hit found at that distance would, and the lane
+// leaves the tree at the first hit inside it: what a visibility test needs, and all it needs.
+IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, float limit, int &closest) {
+    const float4 sp4 = sc.bvh_spheres[slot];
+    V3 oc = ray.o - v3(sp4.x, sp4.y, sp4.z);
+    float half_b = dot(ray.d, oc);
+    float c = len_squared(oc) - sp4.w;
+    float discrim = half_b * half_b - a * c;
+    if (discrim > 0.0f) {  // sphere.rs:31-35, :53
+        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_is_unit(a));
+        if (temp > 0.0f && temp <= limit) closest = (int)sc.bvh_prim[slot];
+    }
+}
+template <bool ANY>
 IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests) {
     const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     uint32_t n_tests = sc.bvh_big_count;
-    for (uint32_t k = 0; k < sc.bvh_big_count; k++) bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
+    for (uint32_t k = 0; k < sc.bvh_big_count; k++) {
+        if (ANY) bvh_sphere_test_any(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
+        else bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
+    }
+    if (ANY && closest >= 0) { tests += n_tests; return; }
     const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
     uint32_t ref = bvh_ref(root_lo, root_hi);
     uint32_t sp = 0u;
@@ -629,9 +649,14 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &
         }
         if (!have) break;
         const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
-        for (uint32_t k = 0; k < count; k++) bvh_sphere_test(sc, first + k, ray, a, closest_t, closest);
+        for (uint32_t k = 0; k < count; k++) {
+            if (ANY) bvh_sphere_test_any(sc, first + k, ray, a, closest_t, closest);
+            else bvh_sphere_test(sc, first + k, ray, a, closest_t, closest);
+        }
         n_tests += count;
-        if (sp != 0u) {
+        if (ANY && closest >= 0) {
+            have = false;
+        } else if (sp != 0u) {
             sp--;
             ref = bvh_pop(st, sp);
         } else {
@@ -651,7 +676,7 @@ IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool activ
     int closest = -1;
     float a = len_squared(ray.d);  // sphere.rs:27 (loop-invariant)
     if (st.bvh) {
-        if (active) bvh_closest(sc, st, ray, a, closest_t, closest, tests);
+        if (active) bvh_closest<false>(sc, st, ray, a, closest_t, closest, tests);
     } else if (st.resident) {
         if (active) scan_window<4>(st.lds, sc.n_prims, 0u, ray, a, closest_t, closest);
         if (active) tests += sc.n_prims;
@@ -1120,18 +1145,35 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
             }
         }
-        float st1;
-        int sp1;
-        scan_closest(sc, st, want1, shadow1, st1, sp1, cnt.sphere_tests);  // scene.rs:134-149
+        bool visible = false;
+        if (st.bvh) {
+            // Scene::ray_hits_point and the map's visibility test (scene.rs:134-149) ask only whether the closest hit lies
+            // beyond a limit: `closest_t > limit` with closest_t = inf when nothing is hit (the map: nothing hit at all,
+            // i.e. limit = inf with equality allowed).  Under a hierarchy that needs no closest hit: it is false iff some
+            // sphere is hit at 0 < t <= limit, or inf > limit is false (limit inf or NaN) -- so the lane leaves the tree at
+            // the first occluder, and the limit culls boxes from the start.
+            const bool env_lane = ENV && env_pick;
+            float limit = __builtin_inff();
+            if (want1 && !env_lane) limit = len(light_pos - shadow1.o) / len(shadow1.d) - IRIS_RAY_EPSILON;
+            int occluder = -1;
+            float lim = limit;
+            if (want1) bvh_closest<true>(sc, st, shadow1, len_squared(shadow1.d), lim, occluder, cnt.sphere_tests);
+            visible = want1 && occluder < 0 && (env_lane || __builtin_inff() > limit);
+        } else {
+            float st1;
+            int sp1;
+            scan_closest(sc, st, want1, shadow1, st1, sp1, cnt.sphere_tests);  // scene.rs:134-149
+            if (want1) {
+                if (ENV && env_pick) {
+                    visible = sp1 < 0;
+                } else {
+                    float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
+                    visible = st1 > target_t - IRIS_RAY_EPSILON;
+                }
+            }
+        }
         if (want1) {
             cnt.rays++;
-            bool visible;
-            if (ENV && env_pick) {
-                visible = sp1 < 0;
-            } else {
-                float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
-                visible = st1 > target_t - IRIS_RAY_EPSILON;
-            }
             if (visible) {
                 V3 shading_wi = world_to_shading(hit, shadow1.d);
                 F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl, MONO);
