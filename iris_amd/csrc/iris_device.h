@@ -595,10 +595,11 @@ IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray,
 // again; a stacked reference whose subtree a later hit has made unreachable fails its children's box tests.
 IRIS_DEV uint32_t bvh_ref(float4 lo, float4 hi) { return __float_as_uint(lo.w) | (__float_as_uint(hi.w) << 29); }
 // ANY = false: the closest hit (closest_t = inf, closest = -1 on entry).
-// ANY = true: is there a hit with 0 < t <= closest_t?  (closest_t = the limit on entry and unchanged on return; closest =
-// the index of one such sphere, or -1.)  The limit culls boxes like a hit found at that distance would, and the lane
-// leaves the tree at the first hit inside it: what a visibility test needs, and all it needs.
-IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, float limit, int &closest) {
+// ANY = true: is there a sphere that a closest-hit scan would prefer to a hit at distance closest_t by primitive `tie`,
+// i.e. one hit at 0 < t < closest_t, or at t == closest_t with a lower index than `tie`?  (closest_t = the limit on entry,
+// unchanged on return; closest = the index of one such sphere, or -1.)  The limit culls boxes like a hit found at that
+// distance would, and the lane leaves the tree at the first such sphere: what a visibility test needs, and all it needs.
+IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, float limit, int tie, int &closest) {
     const float4 sp4 = sc.bvh_spheres[slot];
     V3 oc = ray.o - v3(sp4.x, sp4.y, sp4.z);
     float half_b = dot(ray.d, oc);
@@ -606,15 +607,18 @@ IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {  // sphere.rs:31-35, :53
         float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_is_unit(a));
-        if (temp > 0.0f && temp <= limit) closest = (int)sc.bvh_prim[slot];
+        if (temp > 0.0f && (temp < limit || temp == limit)) {  // at the limit itself only spheres that would win the tie: index < tie
+            const int index = (int)sc.bvh_prim[slot];
+            if (temp < limit || index < tie) closest = index;
+        }
     }
 }
 template <bool ANY>
-IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests) {
+IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests, int tie = 0x7fffffff) {
     const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     uint32_t n_tests = sc.bvh_big_count;
     for (uint32_t k = 0; k < sc.bvh_big_count; k++) {
-        if (ANY) bvh_sphere_test_any(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
+        if (ANY) bvh_sphere_test_any(sc, sc.bvh_big_first + k, ray, a, closest_t, tie, closest);
         else bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
     }
     if (ANY && closest >= 0) { tests += n_tests; return; }
@@ -650,7 +654,7 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &
         if (!have) break;
         const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
         for (uint32_t k = 0; k < count; k++) {
-            if (ANY) bvh_sphere_test_any(sc, first + k, ray, a, closest_t, closest);
+            if (ANY) bvh_sphere_test_any(sc, first + k, ray, a, closest_t, tie, closest);
             else bvh_sphere_test(sc, first + k, ray, a, closest_t, closest);
         }
         n_tests += count;
@@ -1195,12 +1199,34 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             shadow2 = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
             want2 = hero(bs_pdfs) > 0.0f;
         }
-        float st2;
-        int sp2;
-        scan_closest(sc, st, want2, shadow2, st2, sp2, cnt.sphere_tests);  // scene.rs:151-166
+        bool on_light = false;  // the closest hit of the BSDF-sampled ray is the chosen light (the map: nothing is hit)
+        if (st.bvh) {
+            // Scene::ray_hits_object (scene.rs:151-166) is used for one thing: `closest primitive == the light's`.  That
+            // needs the light's own sphere to be hit -- one test, and most rays fail it and are done -- and then no sphere
+            // that the scan would prefer to it: the same visibility query as above, with the light's hit as the limit and
+            // its index as the tie rule.  (The map: no sphere hit at all.)
+            const bool env_lane = ENV && env_pick;
+            const float a2 = len_squared(shadow2.d);
+            float limit = __builtin_inff();
+            bool ask = want2;
+            if (want2 && !env_lane) {
+                limit = sphere_hit_t(stage_sphere(light_sphere), shadow2, a2);
+                ask = limit > 0.0f;
+                if (ask) cnt.sphere_tests++;
+            }
+            int other = -1;
+            float lim = limit;
+            if (ask) bvh_closest<true>(sc, st, shadow2, a2, lim, other, cnt.sphere_tests, env_lane ? 0x7fffffff : light_prim);
+            on_light = ask && other < 0;
+        } else {
+            float st2;
+            int sp2;
+            scan_closest(sc, st, want2, shadow2, st2, sp2, cnt.sphere_tests);  // scene.rs:151-166
+            on_light = want2 && sp2 == light_prim;
+        }
         if (want2) {
             cnt.rays++;
-            if (sp2 == light_prim) {
+            if (on_light) {
                 float lpdf;
                 if (ENV && env_pick) env_eval(sc, shadow2.d, wl, light_emission, lpdf);
                 else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
