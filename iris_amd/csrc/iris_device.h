@@ -1149,7 +1149,9 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
             }
         }
-        bool visible = false;
+        float st1 = __builtin_inff();
+        int sp1 = -1;
+        bool visible_bvh = false;
         if (st.bvh) {
             // Scene::ray_hits_point and the map's visibility test (scene.rs:134-149) ask only whether the closest hit lies
             // beyond a limit: `closest_t > limit` with closest_t = inf when nothing is hit (the map: nothing hit at all,
@@ -1162,22 +1164,21 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             int occluder = -1;
             float lim = limit;
             if (want1) bvh_closest<true>(sc, st, shadow1, len_squared(shadow1.d), lim, occluder, cnt.sphere_tests);
-            visible = want1 && occluder < 0 && (env_lane || __builtin_inff() > limit);
+            visible_bvh = want1 && occluder < 0 && (env_lane || __builtin_inff() > limit);
         } else {
-            float st1;
-            int sp1;
             scan_closest(sc, st, want1, shadow1, st1, sp1, cnt.sphere_tests);  // scene.rs:134-149
-            if (want1) {
-                if (ENV && env_pick) {
-                    visible = sp1 < 0;
-                } else {
-                    float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
-                    visible = st1 > target_t - IRIS_RAY_EPSILON;
-                }
-            }
         }
         if (want1) {
             cnt.rays++;
+            bool visible;
+            if (st.bvh) {
+                visible = visible_bvh;
+            } else if (ENV && env_pick) {
+                visible = sp1 < 0;
+            } else {
+                float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
+                visible = st1 > target_t - IRIS_RAY_EPSILON;
+            }
             if (visible) {
                 V3 shading_wi = world_to_shading(hit, shadow1.d);
                 F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl, MONO);
@@ -1199,7 +1200,9 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             shadow2 = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
             want2 = hero(bs_pdfs) > 0.0f;
         }
-        bool on_light = false;  // the closest hit of the BSDF-sampled ray is the chosen light (the map: nothing is hit)
+        float st2 = __builtin_inff();
+        int sp2 = -1;
+        bool on_light_bvh = false;  // the closest hit of the BSDF-sampled ray is the chosen light (the map: nothing is hit)
         if (st.bvh) {
             // Scene::ray_hits_object (scene.rs:151-166) is used for one thing: `closest primitive == the light's`.  That
             // needs the light's own sphere to be hit -- one test, and most rays fail it and are done -- and then no sphere
@@ -1217,16 +1220,13 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             int other = -1;
             float lim = limit;
             if (ask) bvh_closest<true>(sc, st, shadow2, a2, lim, other, cnt.sphere_tests, env_lane ? 0x7fffffff : light_prim);
-            on_light = ask && other < 0;
+            on_light_bvh = ask && other < 0;
         } else {
-            float st2;
-            int sp2;
             scan_closest(sc, st, want2, shadow2, st2, sp2, cnt.sphere_tests);  // scene.rs:151-166
-            on_light = want2 && sp2 == light_prim;
         }
         if (want2) {
             cnt.rays++;
-            if (on_light) {
+            if (st.bvh ? on_light_bvh : sp2 == light_prim) {
                 float lpdf;
                 if (ENV && env_pick) env_eval(sc, shadow2.d, wl, light_emission, lpdf);
                 else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
