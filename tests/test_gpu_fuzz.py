@@ -73,6 +73,8 @@ def test_random_scene_film_bit_exact(gpu, oracle, seed):
     rng = np.random.RandomState(1000 + seed)
     table = UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff"))
     n_spheres = int(rng.choice([1, 2, 5, 12, 40, 90]))  # >= 65: hierarchy
+    if os.environ.get("IRIS_FUZZ_BIG") == "1":  # a soak of the hierarchy alone: deeper trees
+        n_spheres = int(rng.choice([90, 300, 1000]))
     with_env = bool(seed % 2)
     scene = random_scene(rng, table, n_spheres, with_env)
     integrator = int(rng.randint(0, 4))
