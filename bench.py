@@ -26,17 +26,47 @@ sys.path.insert(0, ROOT)
 F_CAM, F_ISECT, F_FRAME, F_SHADE = 120.0, 27.0, 44.0, 400.0
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (vector)"
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md, HBM3E bandwidth
-# HBM bytes per launch of the path-tracing kernel on the default workload, from the PMC passes of the same
-# command (profiles/r01f_s1_summary.txt: TCC_EA0_WRREQ_64B * 64 + other WRREQ * 32 + TCC_EA0_RDREQ * 64 =
-# 1.915e8 * 64 + 1.7e6 * 32 + 1.31e7 * 64; the writes are 12-byte-per-lane streaming stores, which the counter
-# reads exactly on gfx950).  It is the per-sample result buffer: 12 B x the 1.009e9 samples that are traced
-# and stored (the other 1.114e9 belong to pixels the sky mask proves black) = 1.21e10 algorithmic, plus 0.8e9 read
-# (sky-mask bytes and scene tables that fall out of L2).
-MEASURED_TRAFFIC_DEFAULT_WORKLOAD = 1.31e10
+# roofline.traffic is never typed in: it is read from profiles/traffic.json, which tools/summarize_profile.py writes from
+# the PMC passes of this same command (TCC_EA0_WRREQ/RDREQ, corrected as MI355X_MICROARCH.md prescribes), keyed by the
+# workload; a workload without a committed PMC profile reports null.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def measured_traffic(key):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            e = json.load(f).get(key)
+        return (float(e["bytes_per_launch"]), e["source"]) if e else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def algorithmic_flops(st):
     return F_CAM * st.samples + F_ISECT * st.sphere_tests + (F_FRAME + F_SHADE) * st.bounces
+
+
+def host_cpu():
+    model, cores = "unknown", os.cpu_count() or 1
+    try:
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("model name"):
+                    model = l.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, cores
+
+
+def oracle_build_flags():
+    try:
+        with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+            for l in f:
+                if l.startswith("CFLAGS"):
+                    return l.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(n_threads):
@@ -53,7 +83,9 @@ def cpu_baseline(n_threads):
     cam = O.camera_new([0, 0, 0], np.float32(1.0))
     reps = 3  # about 25 core-seconds in all
     secs = sum(sc.render(cam, O.make_params(w, h, spp), nthreads=n_threads)[2] for _ in range(reps))
+    model, total = host_cpu()
     return {"value": round(reps * w * h * spp / 1e6 / secs, 3), "unit": "Msamples/s", "cores": n_threads, "kind": "port",
+            "host_cpu": model, "host_logical_cpus": total, "threads": n_threads, "build": "gcc " + oracle_build_flags(),
             "sample": "BASELINE config A three times over: default scene 512x512 at 64 spp (3 x 16.8 Msamples), HwssNaive, "
                       "oracle C port, %d threads popping 64x64 tiles, %.2f s in all" % (n_threads, secs)}
 
@@ -145,11 +177,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    default_workload = (args.scene, args.width, args.height, args.spp) == ("s1", 1920, 1080, 1024) and not opts
+    workload_key = "%s_%dx%dx%d%s" % (args.scene, args.width, args.height, args.spp, "".join("_%s=%d" % kv for kv in sorted(opts.items())))
     if rank == 0:
         samples_per_step = args.width * args.height * spp_total
         value = samples_per_step * args.steps / 1e6 / elapsed
-        achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        n_launches = args.steps * max(1, st.chunks)
+        secs = kernel_ms * 1e-3
+        # flops the reference's algorithm executes for this film, and the part of them the kernel executes: the samples of
+        # pixels that the sky mask proves black are never traced (their camera sample and primary scan are not run)
+        flops_skipped = args.steps * (F_CAM + F_ISECT * len(scene.primitives)) * st.sky_samples
+        executed = (flops - flops_skipped) / secs / 1e12 if secs > 0 else 0.0
+        reference_work = flops / secs / 1e12 if secs > 0 else 0.0
+        traffic, traffic_source = measured_traffic(workload_key)
+        # algorithmic bytes = the film (12 B per pixel) + the scene read once (16 B per sphere)
+        algorithmic_bytes = 12.0 * args.width * args.height + 16.0 * len(scene.primitives)
         line = {
             "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
@@ -159,15 +200,20 @@ def main():
                                    ({"s1": "default (scene.rs:43-66, 3 spheres)", "s2": "10k-sphere (hierarchy unless --opt bvh_min_prims=0)", "s3": "glossy/dielectric"}[args.scene[:2]]
                                     + (" + %dx%d HDR environment map" % (args.env_size, args.env_size) if args.scene.endswith("env") else ""),
                                     args.width, args.height, args.spp, spp_total, max_depth),
-                       "width": args.width, "height": args.height, "spp_per_gpu": args.spp, "parallelism": "spp-split x%d" % world},
-            # rank 0's path-tracing kernel, timed with HIP events on its own stream inside the library
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": MEASURED_TRAFFIC_DEFAULT_WORKLOAD if default_workload else None,
-                         "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / args.steps / max(1, st.chunks), 3),
-                         "flop_model": "120*samples + 27*sphere_tests + 444*bounces (exact device counters = the oracle's: what the "
-                                       "reference's algorithm executes; sky_samples of them are proved black by the sky mask and not traced)",
-                         "achieved_traced_only": round((flops - args.steps * (F_CAM + F_ISECT * len(scene.primitives)) * st.sky_samples) / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms > 0 else 0.0},
+                       "width": args.width, "height": args.height, "spp_per_gpu": args.spp, "parallelism": "spp-split x%d" % world,
+                       "ranks": dist.get_world_size() if world > 1 else 1},
+            # rank 0's path-tracing kernel, timed with HIP events on its own stream inside the library.  achieved/frac count
+            # the flops of the work the kernel EXECUTES; achieved_reference_work prices everything the reference would execute
+            "roofline": {"bound": "valu", "achieved": round(executed, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(executed / PEAK_FP32_VALU_TFLOPS, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes": algorithmic_bytes,
+                         "traffic_over_algorithmic": round(traffic / algorithmic_bytes, 1) if traffic else None,
+                         "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / n_launches, 3),
+                         "flop_model": "120*samples + 27*sphere_tests + 444*bounces over exact device counters (= the oracle's), minus "
+                                       "(120 + 27*n_prims)*sky_samples for the camera samples the sky mask proves black and never traces",
+                         "achieved_reference_work": round(reference_work, 3),
+                         "frac_reference_work": round(reference_work / PEAK_FP32_VALU_TFLOPS, 4)},
             # the second kernel of a step, HBM-bound: it reads the 12-byte result of every stored sample once and writes the film
             "roofline_resolve": {"bound": "hbm", "achieved": round(resolve_bytes / (resolve_ms * 1e-3) / 1e9, 1) if resolve_ms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",

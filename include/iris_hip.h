@@ -192,7 +192,7 @@ const char *iris_last_error(const iris_ctx *ctx);
  *   "bvh_leaf"        spheres per leaf of the hierarchy, 1..7 (default 4)
  *   "x_park_max", "x_fire"  register-resident kernel, scenes with non-Lambertian BSDFs and no environment map: hits on
  *                     such surfaces are set aside and shaded together; a mixed iteration runs when this many lanes
- *                     wait with one (default 24) or this many primary ones are queued (default 110)
+ *                     wait with one (1..64, default 24) or this many primary ones are queued (1..129, default 110)
  *   "sky_mask"        1 (default): scenes of up to 64 spheres without an environment map: a pre-pass marks the pixels
  *                     whose camera samples provably hit nothing (conservative cone test in binary64); they are exactly
  *                     black in the reference and are neither traced nor stored; 0: every sample is traced

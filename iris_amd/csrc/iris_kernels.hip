@@ -1445,7 +1445,8 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
         if (value < 0) return fail(c, IRIS_E_ARG, "bvh_min_prims must be >= 0");
         c->bvh_min_prims = value;  // takes effect at the next iris_scene_upload
     } else if (k == "x_park_max") {
-        if (value < 1 || value > 65) return fail(c, IRIS_E_ARG, "x_park_max out of range [1, 65]");
+        // at most 64: once every lane of a wave waits with such a hit, the mixed iteration is the only way forward
+        if (value < 1 || value > 64) return fail(c, IRIS_E_ARG, "x_park_max out of range [1, 64]");
         c->x_park_max = value;
     } else if (k == "x_fire") {
         if (value < 1 || value > 129) return fail(c, IRIS_E_ARG, "x_fire out of range [1, 129]");

@@ -284,6 +284,34 @@ def test_sample_ranges_and_schedules_do_not_change_the_film(gpu, iris_trig):
     assert np.array_equal(bits(big), bits(wantb)) and big.any()
 
 
+def test_second_kind_scheduling_knobs_do_not_change_the_film(gpu, iris_trig):
+    """x_park_max / x_fire (register-resident kernel, general class) only decide WHEN hits on non-Lambertian surfaces are
+    shaded; at their extreme values -- a mixed iteration as soon as one lane waits, or only when all 64 do -- film and
+    counters stay the defaults' bit for bit, and a wave full of waiting lanes still makes progress (S3 is mostly such
+    surfaces).  Values outside the documented ranges are refused."""
+    import iris_amd
+    from iris_amd import Render, Scene
+    from iris_amd.ffi import IrisError
+    scene = Scene.glossy_dielectric()
+    flat = gpu.upload(scene)
+    r = Render(128, 96, 12, scene, max_depth=32)
+    base = gpu.render_film(r)
+    bs = gpu.stats()
+    want, _ = oracle_film(iris_trig, flat, 128, 96, 12, max_depth=32)
+    assert np.array_equal(bits(base), bits(want))
+    for opts in ({"x_park_max": 1}, {"x_park_max": 64}, {"x_fire": 1}, {"x_fire": 129}, {"x_park_max": 64, "x_fire": 129},
+                 {"x_park_max": 1, "x_fire": 1}, {"x_park_max": 64, "x_fire": 129, "reg_blocks_per_cu": 1}):
+        with iris_amd.HipWavefront(0, **opts) as g2:
+            g2.upload(scene)
+            film = g2.render_film(r)
+            st = g2.stats()
+            assert np.array_equal(bits(film), bits(base)), opts
+            assert (st.samples, st.bounces, st.rays, st.sphere_tests) == (bs.samples, bs.bounces, bs.rays, bs.sphere_tests), opts
+    for key, bad in (("x_park_max", 0), ("x_park_max", 65), ("x_fire", 0), ("x_fire", 130)):
+        with pytest.raises(IrisError):
+            gpu.set_option(key, bad)
+
+
 def test_film_vs_libm_trig_oracle(gpu, libm_trig):
     """Against the oracle run with libm sin/cos (the reference's f32::sin/cos on Linux): the two films
     differ only where a 1-ulp sin/cos difference propagated (last-bit noise in most lit pixels, a rare
