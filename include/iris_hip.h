@@ -266,6 +266,21 @@ int iris_render(iris_ctx *ctx, const iris_camera *camera, const iris_render_para
 int iris_render_device(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params,
                        float *d_out_xyz, void *stream);
 
+/* iris_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same film bit for bit, same
+ * stats; but every byte of device memory the render needs beyond the scene, the inputs and d_out_xyz -- the
+ * per-sample result buffer (12 bytes per camera sample of the call), the sky mask, the work counters and the per-wave
+ * queues -- comes out of one static __device__ array of iris_noalloc_workspace_bytes() (64 MiB) that each GPU the
+ * library runs on holds until the process ends, so the call makes no hipMalloc/hipFree (nor does it go through any
+ * allocating library routine).  Limits: scenes the register-resident kernel serves (up to 64 spheres, or a
+ * hierarchy); width*height*spp_count*12 bytes plus the fixed parts must fit the array, else IRIS_E_LIMIT with the
+ * sizes in iris_last_error() -- render the film in several calls over disjoint sample ranges instead.  Every call on a
+ * GPU shares that GPU's array (whatever the context) and finds the last call's contents in it: the call clears what
+ * must start at zero itself, and calls that overlap in time on one GPU race -- serialise them. */
+int iris_render_device_noalloc(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params,
+                               float *d_out_xyz, void *stream);
+size_t iris_noalloc_workspace_bytes(void);
+
 /* The exchange step of a multi-GPU render.  The reference has one shared film behind a RwLock that the
  * worker threads copy their tiles into (main.rs:39, tile.rs:115-121); here each of n GPUs (one context each,
  * all in this process, all on different devices) has rendered a disjoint range of sample indices

@@ -848,6 +848,38 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, Fr
 // Host side: the C ABI
 // =====================================================================================================
 
+// ---- the workspace of iris_render_device_noalloc (include/iris_hip.h) ----
+// Device memory a render needs beyond the scene, its inputs and its output: the per-sample result buffer, the sky mask,
+// the work counters and the launch's item counter, the second hit queue of the general scene class and the deep levels of
+// the traversal stacks.  The allocating entry points hipMalloc these on demand and keep them in the context; the
+// no-alloc entry point carves them out of this array instead, so that it never calls an allocator.  One copy of the array
+// exists per GPU the library runs on (held until the process ends); in host code the name below is only a handle for
+// hipGetSymbolAddress, never an address: everything uses the per-device pointer that scratch_for_device() returns.
+#define IRIS_NOALLOC_SCRATCH_BYTES (64ull << 20)
+static __device__ __align__(256) unsigned char scratch[IRIS_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[MAX_DEVICES] = {};
+// The address of `scratch` on `device`, which must be the current device.  Looked up once per device.
+hipError_t scratch_for_device(int device, unsigned char **out) {
+    *out = nullptr;
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (unsigned char *)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
+
 struct iris_ctx {
     int device = 0;
     int n_cus = 0;
@@ -891,6 +923,8 @@ struct iris_ctx {
     float4 *d_film_acc = nullptr;
     size_t film_cap = 0;
     uint32_t *h_live = nullptr;  // pinned
+    unsigned long long *h_counters = nullptr;  // pinned: the work counters of a render are copied here
+    unsigned char *scratch_ptr = nullptr;  // this device's copy of the static workspace (iris_render_device_noalloc)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     iris_stats stats = {};
 };
@@ -1217,7 +1251,16 @@ int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stre
     return IRIS_OK;
 }
 
-int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *d_out, hipStream_t stream) {
+// Device memory of one render beyond scene, inputs and output.
+struct Workspace {
+    XyzResult *results = nullptr;
+    float4 *film_acc = nullptr;        // running per-pixel sums between sample-range chunks (chunked renders only)
+    unsigned char *sky = nullptr;
+    unsigned long long *counters = nullptr, *work_cursor = nullptr;
+    uint32_t *xq = nullptr, *stack_hi = nullptr;
+};
+
+int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *d_out, hipStream_t stream, bool no_alloc = false) {
     int rc;
     if ((rc = check_params(c, p))) return rc;
     if ((rc = check_scene_for(c, p))) return rc;
@@ -1225,27 +1268,10 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t npix = p->width * p->height;
     c->stats = iris_stats{};
-    // chunking of the sample range so that the per-sample result buffer fits its budget
-    uint64_t max_items = std::min<uint64_t>((uint64_t)c->result_bytes / sizeof(XyzResult), 1ull << 31);
-    if (max_items < npix) return fail(c, IRIS_E_LIMIT, "result_bytes is smaller than one sample of the film");
-    uint32_t spp_per_chunk = (uint32_t)std::min<uint64_t>(max_items / npix, std::max<uint32_t>(p->spp_count, 1u));
-    size_t need_items = (size_t)spp_per_chunk * npix;
-    if (c->results_cap < need_items) {
-        dev_free(c->d_results);
-        c->d_results = nullptr;
-        c->results_cap = 0;
-        if ((rc = dev_alloc(c, &c->d_results, need_items))) return rc;
-        c->results_cap = need_items;
-    }
-    if (c->film_cap < npix) {
-        dev_free(c->d_film_acc);
-        c->d_film_acc = nullptr;
-        c->film_cap = 0;
-        if ((rc = dev_alloc(c, &c->d_film_acc, (size_t)npix))) return rc;
-        c->film_cap = npix;
-    }
     const bool reg = use_register_kernel(c);
+    if (no_alloc && !reg) return fail(c, IRIS_E_LIMIT, "iris_render_device_noalloc serves the scenes of the register-resident kernel only (up to 64 spheres, or a hierarchy)");
     int64_t per_cu = reg ? c->reg_blocks_per_cu : c->blocks_per_cu;
+    if (no_alloc) per_cu = std::min<int64_t>(per_cu, 4);  // a CU holds at most 4 of these workgroups; a smaller grid keeps the per-wave queues small
     if (per_cu == 0) {
         const size_t dyn = (size_t)sphere_cap_for(c) * sizeof(float4);
         switch (p->integrator) {
@@ -1255,39 +1281,89 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         default: per_cu = pool_blocks_per_cu<IRIS_INT_SWSS_SLOW>(c, dyn); break;
         }
     }
-    uint32_t blocks = (uint32_t)(c->n_cus * per_cu);
-    uint32_t spb = (uint32_t)c->slots_per_block;
-    if (!reg && (rc = ensure_pools(c, blocks, spb))) return rc;
+    const uint32_t blocks = (uint32_t)(c->n_cus * per_cu);
+    const uint32_t spb = (uint32_t)c->slots_per_block;
     const uint32_t reg_stack_lds = std::min<uint32_t>(std::max<uint32_t>(c->bvh_depth, 1u), REG_STACK_LDS);
-    if (reg && c->sc.n_bvh_nodes && c->bvh_depth > reg_stack_lds) {  // deeper stack entries of the register kernel: global memory
-        const size_t words = (size_t)blocks * BLOCK * (c->bvh_depth - reg_stack_lds);
-        if (c->stack_hi_words < words) {
+    // sky mask: register kernel on a short list without an environment map
+    const bool use_sky = c->sky_mask && reg && !c->sc.n_bvh_nodes && c->sc.env_w == 0u && p->spp_count != 0u && p->max_depth != 0u;
+    const size_t stack_hi_words = (reg && c->sc.n_bvh_nodes && c->bvh_depth > reg_stack_lds) ? (size_t)blocks * BLOCK * (c->bvh_depth - reg_stack_lds) : 0;
+    const size_t xq_waves = (reg && c->scene_class == IRIS_CLS_GENERAL) ? (size_t)blocks * (BLOCK / 64) : 0;
+    uint32_t spp_per_chunk;
+    Workspace ws;
+    if (no_alloc) {
+        // everything comes out of this device's copy of the static array; one chunk, so no running sums are needed
+        if (!c->scratch_ptr) return fail(c, IRIS_E_STATE, "the static workspace was not found at iris_ctx_create");
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_counters = carve(17 * sizeof(unsigned long long)), o_cursor = carve(sizeof(unsigned long long));
+        const size_t o_sky = carve(use_sky ? npix : 0), o_xq = carve(xq_waves * PQ_FIELDS * XQ_CAP * sizeof(uint32_t));
+        const size_t o_stack = carve(stack_hi_words * sizeof(uint32_t));
+        const size_t o_results = carve((size_t)p->spp_count * npix * sizeof(XyzResult));
+        if (off > IRIS_NOALLOC_SCRATCH_BYTES || (uint64_t)p->spp_count * npix > (1ull << 31))
+            return fail(c, IRIS_E_LIMIT, "iris_render_device_noalloc: this render needs " + std::to_string(off) + " bytes of workspace (12 per camera sample + " +
+                                             std::to_string(o_results) + " fixed for this scene and film), the static workspace holds " +
+                                             std::to_string((unsigned long long)IRIS_NOALLOC_SCRATCH_BYTES));
+        unsigned char *base = c->scratch_ptr;
+        ws.counters = (unsigned long long *)(base + o_counters);
+        ws.work_cursor = (unsigned long long *)(base + o_cursor);
+        ws.sky = base + o_sky;
+        ws.xq = (uint32_t *)(base + o_xq);
+        ws.stack_hi = (uint32_t *)(base + o_stack);
+        ws.results = (XyzResult *)(base + o_results);
+        spp_per_chunk = std::max<uint32_t>(p->spp_count, 1u);
+    } else {
+        // chunking of the sample range so that the per-sample result buffer fits its budget
+        uint64_t max_items = std::min<uint64_t>((uint64_t)c->result_bytes / sizeof(XyzResult), 1ull << 31);
+        if (max_items < npix) return fail(c, IRIS_E_LIMIT, "result_bytes is smaller than one sample of the film");
+        spp_per_chunk = (uint32_t)std::min<uint64_t>(max_items / npix, std::max<uint32_t>(p->spp_count, 1u));
+        size_t need_items = (size_t)spp_per_chunk * npix;
+        if (c->results_cap < need_items) {
+            dev_free(c->d_results);
+            c->d_results = nullptr;
+            c->results_cap = 0;
+            if ((rc = dev_alloc(c, &c->d_results, need_items))) return rc;
+            c->results_cap = need_items;
+        }
+        if (c->film_cap < npix) {
+            dev_free(c->d_film_acc);
+            c->d_film_acc = nullptr;
+            c->film_cap = 0;
+            if ((rc = dev_alloc(c, &c->d_film_acc, (size_t)npix))) return rc;
+            c->film_cap = npix;
+        }
+        if (!reg && (rc = ensure_pools(c, blocks, spb))) return rc;
+        if (c->stack_hi_words < stack_hi_words) {  // deeper stack entries of the register kernel: global memory
             dev_free(c->d_stack_hi);
             c->d_stack_hi = nullptr;
             c->stack_hi_words = 0;
-            if ((rc = dev_alloc(c, &c->d_stack_hi, words))) return rc;
-            c->stack_hi_words = words;
+            if ((rc = dev_alloc(c, &c->d_stack_hi, stack_hi_words))) return rc;
+            c->stack_hi_words = stack_hi_words;
         }
-    }
-    if (reg && c->scene_class == IRIS_CLS_GENERAL && c->xq_waves < (size_t)blocks * (BLOCK / 64)) {  // second hit queue of the general classes
-        dev_free(c->d_xq);
-        c->d_xq = nullptr;
-        c->xq_waves = 0;
-        if ((rc = dev_alloc(c, &c->d_xq, (size_t)blocks * (BLOCK / 64) * PQ_FIELDS * XQ_CAP))) return rc;
-        c->xq_waves = (size_t)blocks * (BLOCK / 64);
-    }
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 17 * sizeof(unsigned long long), stream));
-    // sky mask: register kernel on a short list without an environment map
-    const bool use_sky = c->sky_mask && reg && !c->sc.n_bvh_nodes && c->sc.env_w == 0u && p->spp_count != 0u && p->max_depth != 0u;
-    if (use_sky) {
-        if (c->sky_cap < npix) {
+        if (c->xq_waves < xq_waves) {  // second hit queue of the general classes
+            dev_free(c->d_xq);
+            c->d_xq = nullptr;
+            c->xq_waves = 0;
+            if ((rc = dev_alloc(c, &c->d_xq, xq_waves * PQ_FIELDS * XQ_CAP))) return rc;
+            c->xq_waves = xq_waves;
+        }
+        if (use_sky && c->sky_cap < npix) {
             dev_free(c->d_sky);
             c->d_sky = nullptr;
             c->sky_cap = 0;
             if ((rc = dev_alloc(c, &c->d_sky, (size_t)npix))) return rc;
             c->sky_cap = npix;
         }
-        hipLaunchKernelGGL(k_sky_mask, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, cam_dev(cam), frame_dev(p), c->sc.spheres, c->sc.n_prims, c->d_sky);
+        ws.results = c->d_results;
+        ws.film_acc = c->d_film_acc;
+        ws.sky = c->d_sky;
+        ws.counters = c->d_counters;
+        ws.work_cursor = c->d_work_cursor;
+        ws.xq = c->d_xq;
+        ws.stack_hi = c->d_stack_hi;
+    }
+    HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 17 * sizeof(unsigned long long), stream));
+    if (use_sky) {
+        hipLaunchKernelGGL(k_sky_mask, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, cam_dev(cam), frame_dev(p), c->sc.spheres, c->sc.n_prims, ws.sky);
         HIP_TRY(c, hipGetLastError());
     }
 
@@ -1305,12 +1381,12 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.cam = cam_dev(cam);
         a.fr = frame_dev(p);
         a.pool = c->pool;
-        a.results = c->d_results;
+        a.results = ws.results;
         a.queue = c->d_queue;
         a.blk_cursor = c->d_blk_cursor;
         a.blk_qn = c->d_blk_qn;
         a.live_blocks = c->d_live;
-        a.counters = c->d_counters;
+        a.counters = ws.counters;
         a.npix = npix;
         a.div_npix = make_fastdiv(npix);
         a.div_width = make_fastdiv(p->width);
@@ -1319,15 +1395,15 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.items_per_block = ((a.n_items + blocks * 64u - 1) / (blocks * 64u)) * 64u;  // whole runs of 64
         a.slots_per_block = spb;
         a.sphere_cap = sphere_cap_for(c);
-        a.xq = c->d_xq;
-        a.sky = use_sky ? c->d_sky : nullptr;
-        a.stack_hi = c->d_stack_hi;
+        a.xq = ws.xq;
+        a.sky = use_sky ? ws.sky : nullptr;
+        a.stack_hi = ws.stack_hi;
         a.stack_lds_n = reg_stack_lds;
         if (reg && c->sc.n_bvh_nodes) a.sphere_cap = reg_stack_lds * BLOCK * sizeof(uint32_t) / sizeof(float4);  // LDS for the first levels only
-        a.work_cursor = c->d_work_cursor;
+        a.work_cursor = ws.work_cursor;
         // a run: 2048 items, less for small launches so that every wave still gets several (the tail is one run per wave)
         a.work_run = c->work_run ? (uint32_t)c->work_run : std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
-        if (reg) HIP_TRY(c, hipMemsetAsync(c->d_work_cursor, 0, sizeof(unsigned long long), stream));
+        if (reg) HIP_TRY(c, hipMemsetAsync(ws.work_cursor, 0, sizeof(unsigned long long), stream));
         a.x_park_max = (uint32_t)c->x_park_max;
         a.x_fire = (uint32_t)c->x_fire;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
@@ -1340,8 +1416,8 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, stream));
         bool first = done == 0, last = done + n_s >= p->spp_count;
-        hipLaunchKernelGGL(k_resolve, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, c->d_results, c->d_film_acc, d_out, npix, n_s,
-                           first ? 1 : 0, last ? 1 : 0, weight, (const unsigned char *)(use_sky ? c->d_sky : nullptr));
+        hipLaunchKernelGGL(k_resolve, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, ws.results, ws.film_acc, d_out, npix, n_s,
+                           first ? 1 : 0, last ? 1 : 0, weight, (const unsigned char *)(use_sky ? ws.sky : nullptr));
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev2, stream));
         HIP_TRY(c, hipEventSynchronize(c->ev2));
@@ -1352,13 +1428,13 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         resolve_ms += ms;
         c->stats.chunks += 1;
     }
-    unsigned long long h[17];
-    HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, stream));
+    unsigned long long *h = c->h_counters;  // pinned: the copy needs no staging buffer
+    HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 17 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
 #ifdef IRIS_PHASE_TIMERS
     {
         unsigned long long t[17];
-        (void)hipMemcpy(t, c->d_counters, sizeof t, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(t, ws.counters, sizeof t, hipMemcpyDeviceToHost);
         const double tot = (double)(t[4] + t[5] + t[6] + t[7]);
         std::fprintf(stderr, "[phase timers] extend %.1f%% generate %.1f%% refill %.1f%% shade %.1f%% (wave-cycles %.3g)\n", 100.0 * t[4] / tot,
                      100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, tot);
@@ -1399,6 +1475,8 @@ int iris_ctx_create(int device, iris_ctx **out) {
     if (hipMalloc((void **)&c->d_counters, 17 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&c->d_work_cursor, sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_counters, 17 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+        scratch_for_device(device, &c->scratch_ptr) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
         iris_ctx_destroy(c);
         return IRIS_E_HIP;
@@ -1416,6 +1494,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_sky); dev_free(c->d_work_cursor);
     if (c->h_live) (void)hipHostFree(c->h_live);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -1628,6 +1707,13 @@ int iris_render_device(iris_ctx *c, const iris_camera *cam, const iris_render_pa
     if (!c) return IRIS_E_ARG;
     return render_impl(c, cam, p, d_out, (hipStream_t)stream);
 }
+
+int iris_render_device_noalloc(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *d_out, void *stream) {
+    if (!c) return IRIS_E_ARG;
+    return render_impl(c, cam, p, d_out, (hipStream_t)stream, true);
+}
+
+size_t iris_noalloc_workspace_bytes(void) { return (size_t)IRIS_NOALLOC_SCRATCH_BYTES; }
 
 int iris_render(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *out_xyz) {
     if (!c) return IRIS_E_ARG;

@@ -17,7 +17,8 @@ TRACE_MAX_DEPTH = 64
 # every symbol include/iris_hip.h declares
 EXPORTS = (
     "iris_ctx_create", "iris_ctx_destroy", "iris_last_error", "iris_ctx_set_option", "iris_scene_upload",
-    "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_film_to_rgb",
+    "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_render_device_noalloc",
+    "iris_noalloc_workspace_bytes", "iris_film_to_rgb",
     "iris_get_stats", "iris_allreduce_films", "iris_allreduce_shutdown", "iris_render_multi", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
     "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_envmap_tables", "iris_oct_to_dir", "iris_dir_to_oct",
     "iris_envmap_from_latlong", "iris_envmap_texels_from_rgb", "iris_hdr_read", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
@@ -104,6 +105,8 @@ def load():
         "iris_roughness_to_alpha": (C.c_float, [C.c_float]),
         "iris_render": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(RenderParams), fp]),
         "iris_render_device": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp]),
+        "iris_render_device_noalloc": (C.c_int, [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp]),
+        "iris_noalloc_workspace_bytes": (C.c_size_t, []),
         "iris_film_to_rgb": (C.c_int, [fp, C.c_size_t, fp]),
         "iris_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
         "iris_allreduce_films": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_size_t]),

@@ -115,6 +115,14 @@ class HipWavefront:
                                        C.c_void_p(stream or 0))
         _check(self.L, self.ctx, rc, "iris_render_device")
 
+    def render_film_device_noalloc(self, render: Render, d_out_ptr, spp_begin=0, spp_count=None, stream=None):
+        """iris_render_device_noalloc: the same film, with the workspace taken from the library's static device array
+        (no allocation inside the call; IrisError with the sizes when the render does not fit it)."""
+        p = render.params(spp_begin, spp_count)
+        rc = self.L.iris_render_device_noalloc(self.ctx, C.byref(render.camera.c), C.byref(p), C.c_void_p(d_out_ptr),
+                                               C.c_void_p(stream or 0))
+        _check(self.L, self.ctx, rc, "iris_render_device_noalloc")
+
     def stats(self):
         st = ffi.Stats()
         _check(self.L, self.ctx, self.L.iris_get_stats(self.ctx, C.byref(st)), "iris_get_stats")

@@ -18,7 +18,7 @@ def bits(a):
 def test_library_exports_every_declared_symbol():
     from iris_amd import ffi
     header = open(os.path.join(ROOT, "include", "iris_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int|void|float|uint32_t)\s*\*?\s*(iris_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int|void|float|uint32_t|size_t)\s*\*?\s*(iris_\w+)\s*\(", header, re.M))
     assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
     L = C.CDLL(ffi.LIB_PATH)
     for name in declared:
