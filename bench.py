@@ -102,6 +102,7 @@ def main():
                     help="s1 default scene, s2 10k spheres, s3 glossy/dielectric; ...env: the same under the HDR sky (config E = s3env)")
     ap.add_argument("--env-size", type=int, default=1024, help="environment map is env_size x env_size texels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config-c", action="store_true", help="skip the extra strong-scaling leg (BASELINE config C: 3840x2160 at 4096 spp in all)")
     ap.add_argument("--multi-kernel", action="store_true", help="launch the two stages as separate kernels")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="iris_ctx_set_option tuning knob (repeatable)")
     args = ap.parse_args()
@@ -130,6 +131,8 @@ def main():
         # communicator set-up and the first collective's one-off costs stay out of the timed steps even with --warmup 0
         dist.all_reduce(torch.zeros(1, device="cuda"))
         torch.cuda.synchronize()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[args.scene[:2]]()
     if args.scene.endswith("env"):  # procedural HDR sky through the RGB -> spectrum table (a data fixture; tools/rgb2spec_opt.c makes it)
@@ -176,6 +179,40 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- second leg, same ranks: BASELINE config C, STRONG scaling -- the default scene at 3840x2160 with 4096 spp IN ALL,
+    # rank r renders sample indices [4096 r / N, 4096 (r+1) / N) of every pixel, one all-reduce of the 99.5 MB film.  Reported
+    # as an extra key so that one multi-GPU run of this script yields both the weak (config B per GPU) and the strong curve.
+    config_c = None
+    if args.scene == "s1" and not args.no_config_c and not opts:
+        cw, ch, cspp = 3840, 2160, 4096
+        crender = iris_amd.Render(cw, ch, cspp, scene, max_depth=max_depth)
+        cfilm = torch.zeros((ch, cw, 3), dtype=torch.float32, device="cuda")
+        cbegin, ccount = sample_range(cspp, rank, world)
+
+        def cstep():
+            gpu.render_film_device(crender, cfilm.data_ptr(), spp_begin=cbegin, spp_count=ccount)
+            if world > 1:
+                dist.all_reduce(cfilm, op=dist.ReduceOp.SUM)
+
+        csteps = max(1, min(args.steps, 2))
+        if args.warmup:
+            cstep()
+        fence()
+        c0 = time.perf_counter()
+        for _ in range(csteps):
+            cstep()
+        fence()
+        celapsed = time.perf_counter() - c0
+        if world > 1:
+            t = torch.tensor([celapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            celapsed = float(t.item())
+        config_c = {"workload": "BASELINE config C: default scene 3840x2160, 4096 spp in all, %d spp per rank, spp-split + one all-reduce of the XYZ film" % ccount,
+                    "metric": "Msamples/s", "value": round(cw * ch * cspp * csteps / 1e6 / celapsed, 2), "scaling": "strong",
+                    "ms_per_step": round(celapsed * 1e3 / csteps, 3), "steps": csteps, "n_gpus": world,
+                    "ranks": dist.get_world_size() if world > 1 else 1}
+        del cfilm
 
     workload_key = "%s_%dx%dx%d%s" % (args.scene, args.width, args.height, args.spp, "".join("_%s=%d" % kv for kv in sorted(opts.items())))
     if rank == 0:
@@ -224,6 +261,8 @@ def main():
             "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests, "bvh_depth": st.bvh_depth,
                                   "sky_samples": st.sky_samples},
         }
+        if config_c is not None:
+            line["config_c_strong"] = config_c
         if world == 1 and not args.no_cpu_baseline:
             n_threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
             line["cpu_baseline"] = cpu_baseline(n_threads)

@@ -296,6 +296,11 @@ void iris_allreduce_shutdown(void);
  * device film, iris_allreduce_films sums them, and the total is copied to out_xyz (HOST, width*height*3).
  * Contexts that share a device (a rehearsal on a one-GPU machine) are summed on the host instead. */
 int iris_render_multi(iris_ctx *const *ctxs, int n, const iris_camera *camera, const iris_render_params *params, float *out_xyz);
+/* The split iris_render_multi uses (and iris_amd/distributed.py::sample_range, one process per GPU): share `part` of
+ * `n_parts` is the contiguous block [begin, begin+count) of spp_count sample indices, begin = floor(spp_count*part/n_parts);
+ * blocks differ by at most one sample and cover every index once.  Replaces the tile queue of main.rs:57-64 as the unit
+ * of distribution.  Host only. */
+int iris_sample_range(uint32_t spp_count, uint32_t part, uint32_t n_parts, uint32_t *begin, uint32_t *count);
 
 /* XYZ -> linear RGB, clamped at 0: Xyz::to_rgb_hdr (color.rs:36-41) + the clamp of tile.rs:108-109.
  * Host arrays of 3*n_pixels floats. */

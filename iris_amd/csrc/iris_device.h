@@ -1215,7 +1215,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             if (want2 && !env_lane) {
                 limit = sphere_hit_t(stage_sphere(light_sphere), shadow2, a2);
                 ask = limit > 0.0f;
-                if (ask) cnt.sphere_tests++;
+                cnt.sphere_tests++;  // the test of the light's own sphere is made whether or not it hits
             }
             int other = -1;
             float lim = limit;

@@ -818,6 +818,7 @@ __global__ void __launch_bounds__(BLOCK) k_dbg_trace(SceneDev sc, CamDev cam, Fr
         ps.smp = sampler_new(0u, 0u, 0u, 0u);
     }
     uint32_t n_hits = 0u;
+    if (fr.max_depth == 0u) alive = false;  // `for bounces in 0..0` never runs (hwss_naive.rs:40): no scan, no hit, zero radiance -- as iris_render
     while (__syncthreads_or(alive ? 1 : 0)) {
         float t;
         int prim;
@@ -1820,8 +1821,12 @@ int iris_allreduce_films(iris_ctx *const *ctxs, int n, float *const *d_films, si
         int r = g_rccl.CommInitAll(g_rccl.comms.data(), n, devices.data());
         if (r != 0) { g_rccl.devices.clear(); g_rccl.comms.clear(); g_rccl.streams.clear(); return fail(c0, IRIS_E_RCCL, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
         for (int i = 0; i < n; i++) {
-            HIP_TRY(c0, hipSetDevice(devices[i]));
-            HIP_TRY(c0, hipStreamCreateWithFlags(&g_rccl.streams[i], hipStreamNonBlocking));
+            hipError_t e = hipSetDevice(devices[i]);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_rccl.streams[i], hipStreamNonBlocking);
+            if (e != hipSuccess) {  // leave no half-initialised state behind: the next call starts from scratch
+                rccl_drop_comms();
+                return fail(c0, IRIS_E_HIP, std::string("stream for the film exchange: ") + hipGetErrorString(e));
+            }
         }
     }
     for (int i = 0; i < n; i++) {  // the films were written on other streams: make sure they are complete
@@ -1829,17 +1834,36 @@ int iris_allreduce_films(iris_ctx *const *ctxs, int n, float *const *d_films, si
         HIP_TRY(c0, hipDeviceSynchronize());
     }
     RCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < n; i++) {
-        HIP_TRY(c0, hipSetDevice(devices[i]));
+    std::string group_err;  // every exit after GroupStart goes through GroupEnd
+    int group_code = IRIS_OK;
+    for (int i = 0; i < n && group_code == IRIS_OK; i++) {
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e != hipSuccess) { group_code = IRIS_E_HIP; group_err = std::string("hipSetDevice: ") + hipGetErrorString(e); break; }
         int r = g_rccl.AllReduce(d_films[i], d_films[i], n_floats, NCCL_FLOAT32, NCCL_SUM, g_rccl.comms[i], g_rccl.streams[i]);
-        if (r != 0) { (void)g_rccl.GroupEnd(); return fail(c0, IRIS_E_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r)); }
+        if (r != 0) { group_code = IRIS_E_RCCL; group_err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r); }
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    {
+        int r = g_rccl.GroupEnd();
+        if (group_code == IRIS_OK && r != 0) { group_code = IRIS_E_RCCL; group_err = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r); }
+    }
+    if (group_code != IRIS_OK) {
+        rccl_drop_comms();  // the communicators may hold a half-issued collective
+        return fail(c0, group_code, group_err);
+    }
 #undef RCCL_TRY
     for (int i = 0; i < n; i++) {
         HIP_TRY(c0, hipSetDevice(devices[i]));
         HIP_TRY(c0, hipStreamSynchronize(g_rccl.streams[i]));
     }
+    return IRIS_OK;
+}
+
+// The split of a multi-GPU render: share `part` of `n_parts` of spp_count sample indices, as a contiguous block.
+int iris_sample_range(uint32_t spp_count, uint32_t part, uint32_t n_parts, uint32_t *begin, uint32_t *count) {
+    if (!begin || !count || n_parts == 0 || part >= n_parts) return IRIS_E_ARG;
+    const uint64_t b = (uint64_t)spp_count * part / n_parts, e = (uint64_t)spp_count * (part + 1) / n_parts;
+    *begin = (uint32_t)b;
+    *count = (uint32_t)(e - b);
     return IRIS_OK;
 }
 
@@ -1875,9 +1899,10 @@ int iris_render_multi(iris_ctx *const *ctxs, int n, const iris_camera *cam, cons
         for (int i = 0; i < n; i++) {
             threads.emplace_back([&, i]() {
                 iris_render_params q = *p;
-                const uint64_t b = (uint64_t)p->spp_count * (uint64_t)i / (uint64_t)n, e = (uint64_t)p->spp_count * (uint64_t)(i + 1) / (uint64_t)n;
-                q.spp_begin = p->spp_begin + (uint32_t)b;
-                q.spp_count = (uint32_t)(e - b);
+                uint32_t b = 0, cnt = 0;
+                (void)iris_sample_range(p->spp_count, (uint32_t)i, (uint32_t)n, &b, &cnt);
+                q.spp_begin = p->spp_begin + b;
+                q.spp_count = cnt;
                 rcs[i] = render_impl(ctxs[i], cam, &q, d_films[i], nullptr);
             });
         }

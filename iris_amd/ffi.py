@@ -19,7 +19,7 @@ EXPORTS = (
     "iris_ctx_create", "iris_ctx_destroy", "iris_last_error", "iris_ctx_set_option", "iris_scene_upload",
     "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_render_device_noalloc",
     "iris_noalloc_workspace_bytes", "iris_film_to_rgb",
-    "iris_get_stats", "iris_allreduce_films", "iris_allreduce_shutdown", "iris_render_multi", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
+    "iris_get_stats", "iris_allreduce_films", "iris_allreduce_shutdown", "iris_render_multi", "iris_sample_range", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
     "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_envmap_tables", "iris_oct_to_dir", "iris_dir_to_oct",
     "iris_envmap_from_latlong", "iris_envmap_texels_from_rgb", "iris_hdr_read", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
 )
@@ -112,6 +112,7 @@ def load():
         "iris_allreduce_films": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_size_t]),
         "iris_allreduce_shutdown": (None, []),
         "iris_render_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(Camera), C.POINTER(RenderParams), fp]),
+        "iris_sample_range": (C.c_int, [u32, u32, u32, u32p, u32p]),
         "iris_upsample_table_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
         "iris_upsample_table_free": (None, [vp]),
         "iris_upsample_table_resolution": (C.c_uint32, [vp]),

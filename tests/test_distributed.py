@@ -31,6 +31,24 @@ def test_sample_range_partitions_every_index_once():
         sample_range(8, 2, 2)
 
 
+def test_native_split_equals_the_python_split():
+    """iris_render_multi (one process, n GPUs) and bench.py / render_distributed (one process per GPU) must hand out the
+    same blocks of sample indices: iris_sample_range (the C ABI's split, host code -- no GPU needed) against
+    distributed.sample_range for ragged and degenerate counts."""
+    import ctypes as C
+    from iris_amd import ffi
+    from iris_amd.distributed import sample_range
+    L = ffi.load()
+    b, n = C.c_uint32(), C.c_uint32()
+    for spp in (0, 1, 5, 7, 100, 1023, 4096, 70_003, 2**32 - 1):
+        for world in (1, 2, 3, 5, 8, 16):
+            for rank in range(world):
+                assert L.iris_sample_range(spp, rank, world, C.byref(b), C.byref(n)) == 0
+                assert (b.value, n.value) == sample_range(spp, rank, world)
+    assert L.iris_sample_range(8, 2, 2, C.byref(b), C.byref(n)) == ffi.IRIS_OK - 1  # IRIS_E_ARG
+    assert L.iris_sample_range(8, 0, 0, C.byref(b), C.byref(n)) == -1
+
+
 @pytest.mark.parametrize("world,spp", [(2, 8), (3, 7)])
 def test_gloo_allreduce_of_partial_films(tmp_path, oracle, world, spp):
     import torch.multiprocessing as mp

@@ -624,3 +624,6 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["counters_per_step"]["samples"] == 320 * 180 * 8  # rank 0's share: 8 of the 16 spp
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    assert d["config"]["ranks"] == 2
+    c = d["config_c_strong"]  # the strong-scaling leg: 3840x2160 at 4096 spp in all, 2048 per rank here
+    assert c["scaling"] == "strong" and c["ranks"] == 2 and c["n_gpus"] == 2 and c["value"] > 0 and "2048 spp per rank" in c["workload"]
