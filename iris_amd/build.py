@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libiris_hip.so")
 SOURCES = [os.path.join(CSRC, "iris_kernels.hip"), os.path.join(CSRC, "iris_host.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "tables", "cie1931.inc"),
+DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "tables", "cie_cmf.inc"),
                   os.path.join(CSRC, "tables", "sobol_rev16.inc"), os.path.join(HERE, "..", "include", "iris_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -17,7 +17,7 @@
 #include "../../include/iris_hip.h"
 
 #define IRIS_TABLE_QUAL __device__ const
-#include "tables/cie1931.inc"
+#include "tables/cie_cmf.inc"
 #include "tables/sobol_rev16.inc"
 #define IRIS_SOBOL_SETS 64u
 

@@ -21,7 +21,7 @@
 #include <time.h>
 
 #define IRIS_TABLE_QUAL const
-#include "tables/cie1931.inc"
+#include "tables/cie_cmf.inc"
 #include "tables/sobol_rev16.inc"
 
 /* ------------------------------------------------------------------------ */

@@ -25,6 +25,58 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def _c_prototypes(header):
+    """name -> number of parameters, for every function include/iris_hip.h declares"""
+    text = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    out = {}
+    for m in re.finditer(r"(?:const\s+char\s*\*|int|void|float|uint32_t|size_t)\s*\*?\s*(iris_\w+)\s*\(([^;{]*?)\)\s*;", text, re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def _c_struct_fields(header, name):
+    text = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    body = re.search(r"typedef\s+struct\s*\{([^}]*)\}\s*%s\s*;" % name, text, re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1].lstrip("*")))
+    return fields
+
+
+def test_rust_sys_crate_declares_the_same_abi():
+    """ffi/iris-hip-sys/src/lib.rs (the binding a maintainer adds to iris; shipped as source, there is no Rust toolchain
+    here): every `pub fn` is a symbol of include/iris_hip.h with the same number of parameters and vice versa, and every
+    #[repr(C)] struct lists the header's fields in the header's order."""
+    header = open(os.path.join(ROOT, "include", "iris_hip.h")).read()
+    rust = open(os.path.join(ROOT, "ffi", "iris-hip-sys", "src", "lib.rs")).read()
+    rust = re.sub(r"//[^\n]*", "", rust)
+    want = _c_prototypes(header)
+    got = {}
+    for m in re.finditer(r"pub\s+fn\s+(iris_\w+)\s*\(([^)]*)\)", rust, re.S):
+        args = m.group(2).strip()
+        got[m.group(1)] = len([a for a in args.split(",") if a.strip()]) if args else 0
+    assert got == want, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)}
+    from iris_amd import ffi
+    assert set(got) == set(ffi.EXPORTS)
+    for name in ("iris_sphere", "iris_spectrum", "iris_bsdf", "iris_light", "iris_envmap_desc", "iris_scene_desc", "iris_camera",
+                 "iris_render_params", "iris_stats", "iris_trace"):
+        body = re.search(r"pub\s+struct\s+%s\s*\{([^}]*)\}" % name, rust, re.S).group(1)
+        fields = re.findall(r"pub\s+(\w+)\s*:", body)
+        assert fields == _c_struct_fields(header, name), name
+    # the wrapper type and the patch it needs are there, and use only declared symbols
+    wrapper = open(os.path.join(ROOT, "ffi", "hip_wavefront.rs")).read()
+    for sym in set(re.findall(r"sys::(iris_\w+)\s*\(", wrapper)):
+        assert sym in want, sym
+    assert os.path.exists(os.path.join(ROOT, "ffi", "iris_patch", "accessors.patch"))
+    for f in ("Cargo.toml", "build.rs"):
+        assert os.path.exists(os.path.join(ROOT, "ffi", "iris-hip-sys", f))
+
+
 def test_abi_struct_sizes():
     from iris_amd import ffi
     assert C.sizeof(ffi.Sphere) == 16 and C.sizeof(ffi.Spectrum) == 20 and C.sizeof(ffi.Bsdf) == 20

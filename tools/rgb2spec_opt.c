@@ -6,9 +6,11 @@
  * It restates the published optimiser of Jakob & Hanika, "A Low-Dimensional Function Space for Efficient
  * Spectral Upsampling" (EG 2019; the reference cites it at upsample.rs:1): for every cell of a
  * 3 x res^3 grid over (max channel, other two channels scaled by it, brightness) find by Gauss-Newton the
- * three coefficients whose sigmoid(polynomial) reflectance spectrum, lit by D65 and seen through the CIE 1931
- * observer, reproduces the cell's sRGB colour in CIE Lab.  Data: the CIE 1931 2-degree observer at 5 nm
- * (every fifth entry of the reference's own 1 nm tables, color.rs:145-1565) and the CIE D65 illuminant
+ * three coefficients whose sigmoid(polynomial) reflectance spectrum, lit by D65 and seen through the reference's
+ * own observer, reproduces the cell's sRGB colour in CIE Lab.  Data: every fifth entry of the reference's 1 nm
+ * colour-matching tables (color.rs:145-1565; by their values the CIE 1964 10-degree observer -- NOT the CIE 1931
+ * 2-degree observer that Jakob & Hanika's published tool, and hence the reference's missing data/srgb.coeff, used,
+ * which is why the golden vector of upsample.rs:175-185 is not reproduced) and the CIE D65 illuminant
  * (published 10 nm values, midpoints in between, as the 5 nm CIE table has them).
  *
  *   rgb2spec_opt <resolution> <out-file>                  full table (resolution 64 = the reference's file)
@@ -26,7 +28,7 @@
 #include <string.h>
 
 #define IRIS_TABLE_QUAL const
-#include "../oracle/tables/cie1931.inc"
+#include "../oracle/tables/cie_cmf.inc"
 
 #define LAMBDA_MIN 360.0
 #define LAMBDA_MAX 830.0
