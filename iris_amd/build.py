@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libiris_hip.so")
-SOURCES = [os.path.join(CSRC, "iris_kernels.hip"), os.path.join(CSRC, "iris_host.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "tables", "cie_cmf.inc"),
+SOURCES = [os.path.join(CSRC, "iris_kernels.hip"), os.path.join(CSRC, "iris_host.cpp"), os.path.join(CSRC, "iris_bvh_build.cpp")]
+DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "iris_bvh_build.h"), os.path.join(CSRC, "tables", "cie_cmf.inc"),
                   os.path.join(CSRC, "tables", "sobol_rev16.inc"), os.path.join(HERE, "..", "include", "iris_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -40,6 +40,14 @@ def build(force=False, extra=()):
     return LIB_PATH
 
 
+def build_experiment(out_path, extra=()):
+    """A side build for tuning experiments (IRIS_HIP_LIB=<out_path> selects it): HwssNaive kernels only, which compiles
+    four times faster.  Never the shipped library."""
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    subprocess.check_call([HIPCC] + FLAGS + ["-DIRIS_EXPERIMENT_INTEG0"] + list(extra) + ["-o", out_path] + SOURCES)
+    return out_path
+
+
 # The C++ host driver above the C ABI (iris_amd/host/: the mirror of the reference's main.rs + scene.rs).
 CLI_PATH = os.path.join(LIB_DIR, "iris_render")
 CLI_SOURCES = [os.path.join(HERE, "host", "iris_main.cpp")]
@@ -56,5 +64,9 @@ def build_cli(force=False):
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
-    print(path)
+    if "--integ0" in sys.argv:  # python -m iris_amd.build --integ0 <out.so> [-Dflags...]
+        i = sys.argv.index("--integ0")
+        print(build_experiment(sys.argv[i + 1], extra=[a for a in sys.argv[i + 2:] if a.startswith("-")]))
+    else:
+        path = build(force="--force" in sys.argv, extra=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
+        print(path)

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "../../include/iris_hip.h"
+#include "iris_bvh_build.h"  // IRIS_BVH_STACK
 
 #define IRIS_TABLE_QUAL __device__ const
 #include "tables/cie_cmf.inc"
@@ -542,7 +543,6 @@ IRIS_DEV void bvh_push(const SphereStage &st, uint32_t sp, uint32_t ref) {
 IRIS_DEV uint32_t bvh_pop(const SphereStage &st, uint32_t sp) {
     return sp < st.stack_lds_n ? st.stack[sp * IRIS_BLOCK] : st.stack_hi[(size_t)(sp - st.stack_lds_n) * st.stack_hi_stride];
 }
-#define IRIS_BVH_STACK 24u   // entries per lane; the host builds no hierarchy deeper than this
 
 // One pass over `n` staged spheres (n real ones, followed by fillers up to a multiple of IRIS_SCAN_PAD),
 // B at a time: the B LDS reads of a batch are issued together, so their latency is paid once per batch.

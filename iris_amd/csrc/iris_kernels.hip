@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "iris_device.h"
+#include "iris_bvh_build.h"
 
 
 using namespace iris;
@@ -934,163 +935,11 @@ namespace {
 
 constexpr uint32_t SPHERE_CAP = 1024;  // LDS window: 16 KiB of float4 (three pool-kernel workgroups per CU stay resident)
 
-// ---- host-side hierarchy build: balanced median splits of the sphere centres along the widest axis ----
-struct Bvh {
-    std::vector<float4> nodes;    // two per node: (lo, first), (hi, count)
-    std::vector<float4> spheres;  // (cx, cy, cz, r * r) in leaf order
-    std::vector<uint32_t> prim;
-    uint32_t depth = 0;
-    uint32_t n_big = 0;  // the last n_big leaf-ordered spheres are outside the tree
-    uint32_t leaf = 4;   // spheres per leaf, <= 7: a node reference keeps the count in three bits, the first sphere in 29 (option bvh_leaf)
-};
-float4 with_bits(float x, float y, float z, uint32_t w) {
-    float f;
-    std::memcpy(&f, &w, 4);
-    return make_float4(x, y, z, f);
-}
-struct BvhBounds {
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    void add(const float c[3], float r) {
-        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], c[k] - r); hi[k] = std::max(hi[k], c[k] + r); }
-    }
-    float half_area() const {
-        const float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
-        return d[0] < 0.0f ? 0.0f : d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
-    }
-};
-float centre_of(const iris_sphere &s, int axis) { return axis == 0 ? s.cx : (axis == 1 ? s.cy : s.cz); }
-
-// One node over order[begin, end): binned surface-area-heuristic split (median split when `sah` is off or the
-// bins cannot separate the centres).
-void build_bvh_node(const iris_sphere *sp, std::vector<uint32_t> &order, uint32_t begin, uint32_t end, uint32_t node, uint32_t depth, bool sah, Bvh &out) {
-    BvhBounds box, cen;
-    for (uint32_t i = begin; i < end; i++) {
-        const iris_sphere &s = sp[order[i]];
-        const float c[3] = {s.cx, s.cy, s.cz};
-        box.add(c, std::fabs(s.r));
-        cen.add(c, 0.0f);
-    }
-    // Inflate: a hit point computed in f32 lies within a few ulps of the sphere, i.e. of the exact box; the pad is
-    // some thousand ulps of the largest coordinate, so no sphere that the list scan would report is ever culled.
-    float mag = 1.0f;
-    for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(std::fabs(box.lo[k]), std::fabs(box.hi[k])));
-    const float pad = 1e-3f * mag;
-    const float lo[3] = {box.lo[0] - pad, box.lo[1] - pad, box.lo[2] - pad}, hi[3] = {box.hi[0] + pad, box.hi[1] + pad, box.hi[2] + pad};
-    out.depth = std::max(out.depth, depth);
-    if (end - begin <= out.leaf) {
-        std::sort(order.begin() + begin, order.begin() + end);  // leaf: spheres in ascending primitive order
-        out.nodes[2 * node] = with_bits(lo[0], lo[1], lo[2], begin);
-        out.nodes[2 * node + 1] = with_bits(hi[0], hi[1], hi[2], end - begin);
-        return;
-    }
-    int axis = 0;
-    for (int k = 1; k < 3; k++)
-        if (cen.hi[k] - cen.lo[k] > cen.hi[axis] - cen.lo[axis]) axis = k;
-    uint32_t mid = begin + (end - begin) / 2;
-    bool split_done = false;
-    if (sah) {
-        constexpr int BINS = 16;
-        float best_cost = INFINITY, best_pos = 0.0f;
-        int best_axis = -1;
-        for (int ax = 0; ax < 3; ax++) {
-            const float c0 = cen.lo[ax], ext = cen.hi[ax] - cen.lo[ax];
-            if (!(ext > 0.0f)) continue;
-            BvhBounds bin_box[BINS];
-            uint32_t bin_n[BINS] = {};
-            for (uint32_t i = begin; i < end; i++) {
-                const iris_sphere &s = sp[order[i]];
-                const int bi = std::min(BINS - 1, (int)((centre_of(s, ax) - c0) / ext * BINS));
-                const float c[3] = {s.cx, s.cy, s.cz};
-                bin_box[bi].add(c, std::fabs(s.r));
-                bin_n[bi]++;
-            }
-            float right_area[BINS];
-            BvhBounds acc;
-            for (int k = BINS - 1; k > 0; k--) {
-                for (int d = 0; d < 3; d++) { acc.lo[d] = std::min(acc.lo[d], bin_box[k].lo[d]); acc.hi[d] = std::max(acc.hi[d], bin_box[k].hi[d]); }
-                right_area[k] = acc.half_area();
-            }
-            BvhBounds left;
-            uint32_t n_left = 0;
-            for (int k = 0; k < BINS - 1; k++) {
-                for (int d = 0; d < 3; d++) { left.lo[d] = std::min(left.lo[d], bin_box[k].lo[d]); left.hi[d] = std::max(left.hi[d], bin_box[k].hi[d]); }
-                n_left += bin_n[k];
-                const uint32_t n_right = (end - begin) - n_left;
-                if (n_left == 0 || n_right == 0) continue;
-                const float cost = left.half_area() * (float)n_left + right_area[k + 1] * (float)n_right;
-                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_pos = c0 + ext * (float)(k + 1) / BINS; }
-            }
-        }
-        if (best_axis >= 0) {
-            auto it = std::partition(order.begin() + begin, order.begin() + end, [&](uint32_t a) {
-                const float c0 = cen.lo[best_axis], ext = cen.hi[best_axis] - cen.lo[best_axis];
-                return std::min(15, (int)((centre_of(sp[a], best_axis) - c0) / ext * 16)) < (int)std::lround((best_pos - c0) / ext * 16);
-            });
-            mid = (uint32_t)(it - order.begin());
-            split_done = mid > begin && mid < end;
-        }
-    }
-    if (!split_done) {
-        mid = begin + (end - begin) / 2;
-        std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](uint32_t a, uint32_t b) {
-            const float ca = centre_of(sp[a], axis), cb = centre_of(sp[b], axis);
-            return ca < cb || (ca == cb && a < b);
-        });
-    }
-    const uint32_t left = (uint32_t)(out.nodes.size() / 2);
-    out.nodes.resize(out.nodes.size() + 4);
-    out.nodes[2 * node] = with_bits(lo[0], lo[1], lo[2], left);
-    out.nodes[2 * node + 1] = with_bits(hi[0], hi[1], hi[2], 0u);
-    build_bvh_node(sp, order, begin, mid, left, depth + 1, sah, out);
-    build_bvh_node(sp, order, mid, end, left + 1, depth + 1, sah, out);
-}
-// Spheres that span a large part of the scene (a ground sphere, a big light) would put a scene-sized box at every
-// level of their branch; they are kept out of the tree and tested first, one by one (at most BVH_MAX_BIG).
-constexpr uint32_t BVH_MAX_BIG = 16;
-// false: no hierarchy (non-finite geometry, nothing left for a tree) -- the list scan is used instead
-bool build_bvh(const iris_sphere *sp, uint32_t n, uint32_t leaf, Bvh &out) {
-    out.leaf = leaf;
-    BvhBounds cen;
-    for (uint32_t i = 0; i < n; i++) {
-        if (!std::isfinite(sp[i].cx) || !std::isfinite(sp[i].cy) || !std::isfinite(sp[i].cz) || !std::isfinite(sp[i].r)) return false;
-        const float c[3] = {sp[i].cx, sp[i].cy, sp[i].cz};
-        cen.add(c, 0.0f);
-    }
-    // "big": radius above a quarter of the median-ish scale of the centres' bounding box
-    const float extent = std::max(cen.hi[0] - cen.lo[0], std::max(cen.hi[1] - cen.lo[1], cen.hi[2] - cen.lo[2]));
-    std::vector<uint32_t> by_radius(n);
-    for (uint32_t i = 0; i < n; i++) by_radius[i] = i;
-    const uint32_t n_cand = std::min(n, BVH_MAX_BIG);
-    std::partial_sort(by_radius.begin(), by_radius.begin() + n_cand, by_radius.end(),
-                      [&](uint32_t a, uint32_t b) { return std::fabs(sp[a].r) > std::fabs(sp[b].r) || (std::fabs(sp[a].r) == std::fabs(sp[b].r) && a < b); });
-    std::vector<uint32_t> big;
-    std::vector<char> is_big(n, 0);
-    for (uint32_t k = 0; k < n_cand; k++)
-        if (std::fabs(sp[by_radius[k]].r) > 0.125f * extent) { big.push_back(by_radius[k]); is_big[by_radius[k]] = 1; }
-    std::sort(big.begin(), big.end());
-    std::vector<uint32_t> order;
-    for (uint32_t i = 0; i < n; i++)
-        if (!is_big[i]) order.push_back(i);
-    if (order.empty() || n >= (1u << 29)) return false;
-    for (int attempt = 0; attempt < 2; attempt++) {  // surface-area heuristic first; balanced medians if that came out too deep
-        out.nodes.assign(2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        out.depth = 0;
-        std::vector<uint32_t> work = order;
-        build_bvh_node(sp, work, 0, (uint32_t)work.size(), 0, 1, attempt == 0, out);
-        if (out.depth <= IRIS_BVH_STACK) { order = work; break; }
-        if (attempt == 1) return false;
-    }
-    // leaf-ordered arrays: the tree's spheres first (node `first` fields index them), the big ones behind them
-    out.n_big = (uint32_t)big.size();
-    out.prim = order;
-    out.prim.insert(out.prim.end(), big.begin(), big.end());
-    out.spheres.resize(n);
-    for (uint32_t i = 0; i < n; i++) {
-        const iris_sphere &s = sp[out.prim[i]];
-        out.spheres[i] = make_float4(s.cx, s.cy, s.cz, s.r * s.r);
-    }
-    return true;
-}
+// The host-side hierarchy build lives in iris_bvh_build.cpp (plain C++: it is also compiled, with sanitizers, into the
+// CPU test driver tests/host_san/).
+using iris_host::Bvh;
+using iris_host::build_bvh;
+static_assert(sizeof(iris_host::Float4) == sizeof(float4), "the builder's records are uploaded as float4");
 
 // one correctly rounded f32 division on the host (what the kernels' `/` is: -ffp-contract=off, IEEE divide)
 float iris_f32_div(float a, float b) {
@@ -1277,9 +1126,13 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         const size_t dyn = (size_t)sphere_cap_for(c) * sizeof(float4);
         switch (p->integrator) {
         case IRIS_INT_HWSS_NAIVE: per_cu = pool_blocks_per_cu<IRIS_INT_HWSS_NAIVE>(c, dyn); break;
+#ifndef IRIS_EXPERIMENT_INTEG0  // experiment builds (python -m iris_amd.build --integ0 -o ...): HwssNaive kernels only
         case IRIS_INT_HWSS_SLOW: per_cu = pool_blocks_per_cu<IRIS_INT_HWSS_SLOW>(c, dyn); break;
         case IRIS_INT_SWSS_NAIVE: per_cu = pool_blocks_per_cu<IRIS_INT_SWSS_NAIVE>(c, dyn); break;
         default: per_cu = pool_blocks_per_cu<IRIS_INT_SWSS_SLOW>(c, dyn); break;
+#else
+        default: return fail(c, IRIS_E_ARG, "this experiment build holds the HwssNaive kernels only");
+#endif
         }
     }
     const uint32_t blocks = (uint32_t)(c->n_cus * per_cu);
@@ -1410,9 +1263,13 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
         switch (p->integrator) {
         case IRIS_INT_HWSS_NAIVE: rc = launch_chunk<IRIS_INT_HWSS_NAIVE>(c, a, blocks, stream); break;
+#ifndef IRIS_EXPERIMENT_INTEG0  // experiment builds (python -m iris_amd.build --integ0 -o ...): HwssNaive kernels only
         case IRIS_INT_HWSS_SLOW: rc = launch_chunk<IRIS_INT_HWSS_SLOW>(c, a, blocks, stream); break;
         case IRIS_INT_SWSS_NAIVE: rc = launch_chunk<IRIS_INT_SWSS_NAIVE>(c, a, blocks, stream); break;
         default: rc = launch_chunk<IRIS_INT_SWSS_SLOW>(c, a, blocks, stream); break;
+#else
+        default: return fail(c, IRIS_E_ARG, "this experiment build holds the HwssNaive kernels only");
+#endif
         }
         if (rc) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, stream));
@@ -2025,9 +1882,13 @@ int iris_dbg_trace(iris_ctx *c, const iris_camera *cam, const iris_render_params
     FrameDev fd = frame_dev(p);
     switch (p->integrator) {
     case IRIS_INT_HWSS_NAIVE: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_HWSS_NAIVE>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
+#ifndef IRIS_EXPERIMENT_INTEG0  // experiment builds (python -m iris_amd.build --integ0 -o ...): HwssNaive kernels only
     case IRIS_INT_HWSS_SLOW: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_HWSS_SLOW>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
     case IRIS_INT_SWSS_NAIVE: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_SWSS_NAIVE>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
     default: hipLaunchKernelGGL(k_dbg_trace<IRIS_INT_SWSS_SLOW>, grid, block, dyn, nullptr, c->sc, cd, fd, cap, (const uint32_t *)dx.p, n, (iris_trace *)dtr.p); break;
+#else
+    default: return fail(c, IRIS_E_ARG, "this experiment build holds the HwssNaive kernels only");
+#endif
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpy(out, dtr.p, sizeof(iris_trace) * (size_t)n, hipMemcpyDeviceToHost));
