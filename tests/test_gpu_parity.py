@@ -330,25 +330,56 @@ def test_film_vs_libm_trig_oracle(gpu, libm_trig):
     assert off.any(axis=2).mean() < 0.02
 
 
-def test_converged_image_tolerance(gpu, libm_trig):
-    """north_star tolerance: relative MSE of the GPU film at N spp against a 16x-spp CPU reference below
-    1e-3 (on the Y channel of lit pixels), plus a per-pixel z-test of the two means."""
-    from iris_amd import Render, Scene
-    scene = Scene.dummy()
+def image_gate(gpu, O, scene, w, h, spp, max_depth, n_parts=32, ref_parts=16):
+    """north_star's image gate: the GPU film at `spp` against the CPU oracle (libm sin/cos, what the
+    reference calls) at 16x spp over DISJOINT sample indices [spp, 17 spp), so the two are independent estimates.
+    (1) relative MSE over all three XYZ channels;
+    (2) per pixel and channel z = (gpu - ref) / sqrt(se_gpu^2 + se_ref^2), both standard errors estimated from disjoint
+        sample-range parts of the respective render (32 GPU parts, 16 oracle parts of `spp` samples each).
+    Returns (rel_mse, fraction of |z| > 3, mean z^2, mean min(z^2, 16), median z^2)."""
+    from iris_amd import Render
     flat = gpu.upload(scene)
-    w = h = 48
-    film = gpu.render_film(Render(w, h, 1024, scene))
-    ref, _ = oracle_film(libm_trig, flat, w, h, 16384 // 4)  # 4096 spp reference (4x; 16x would take minutes on CPU)
-    y, yr = film[..., 1].astype(np.float64), ref[..., 1].astype(np.float64)
-    rel_mse = np.mean((y - yr) ** 2) / np.mean(yr ** 2)
-    assert rel_mse < 1e-3
-    # z-test: per-pixel difference of means against the Monte-Carlo standard error estimated from
-    # independent sample ranges of the GPU render
-    parts = np.stack([gpu.render_film(Render(w, h, 1024, scene), spp_begin=k * 128, spp_count=128)[..., 1] * 8.0 for k in range(8)]).astype(np.float64)
-    se = parts.std(axis=0, ddof=1) / np.sqrt(8.0)
+    r = Render(w, h, spp, scene, max_depth=max_depth)
+    film = gpu.render_film(r).astype(np.float64)
+    osc = O.OracleScene(flat)
+    cam = O.camera_new([0, 0, 0], np.float32(w) / np.float32(h))
+    rparts = np.stack([osc.render(cam, O.make_params(w, h, spp, spp_begin=spp * (1 + k), spp_count=spp, max_depth=max_depth), nthreads=16)[0].astype(np.float64)
+                       for k in range(ref_parts)])
+    ref = rparts.mean(axis=0)
+    se_ref = rparts.std(axis=0, ddof=1) / np.sqrt(ref_parts)
+    rel_mse = float(np.sum((film - ref) ** 2) / np.sum(ref ** 2))
+    per = spp // n_parts
+    parts = np.stack([gpu.render_film(r, spp_begin=k * per, spp_count=per).astype(np.float64) * n_parts for k in range(n_parts)])
+    se_gpu = parts.std(axis=0, ddof=1) / np.sqrt(n_parts)
+    se = np.sqrt(se_gpu ** 2 + se_ref ** 2)
     lit = se > 0
-    z = (y - yr)[lit] / (se[lit] * np.sqrt(1.0 + 0.25))
-    assert np.mean(np.abs(z) > 4.0) < 0.01
+    assert lit.mean() > 0.3
+    z2 = ((film - ref)[lit] / se[lit]) ** 2
+    return rel_mse, float(np.mean(z2 > 9.0)), float(np.mean(z2)), float(np.mean(np.minimum(z2, 16.0))), float(np.median(z2))
+
+
+@pytest.mark.parametrize("scene_name,w,h,spp,max_depth", [("s1", 48, 48, 1024, 15), ("s3", 40, 40, 2048, 32), ("s3env", 40, 40, 2048, 32)])
+def test_converged_image_tolerance(gpu, libm_trig, scene_name, w, h, spp, max_depth):
+    """The image gate on the default scene, on the glossy/dielectric scene at depth 32 and on the same under the HDR sky:
+    relative MSE < 1e-3 (all three channels), fewer than 1 % of the z values beyond 3 sigma (0.27 % expected) and mean z^2
+    in [0.8, 1.25] -- a bias of one standard error would add 1 to mean z^2.  Two documented departures, both measured on
+    unbiased renders (the GPU film equals the oracle's bit for bit under the specified sin/cos):
+    * S3 without the sky is heavy-tailed (rare bright dispersion/caustic paths dominate ~2 % of the pixel-channels, whose
+      2048-sample means are far from normal and whose variance estimates miss the tail): measured 1.7 % beyond 3, mean z^2 1.34,
+      median z^2 0.54 (chi^2_1: 0.455).  Its bounds are 3 %, a clipped mean (z^2 capped at 16) below 1.6 and median below 0.8;
+      a one-sigma bias would put the clipped mean above 2 and the median above 1.
+    * Under the sky the Owen-scrambled Sobol points beat independent ones (mean z^2 0.72): the lower bound is 0.5."""
+    from iris_amd import EnvMap, Scene, UpsampleTable
+    scene = {"s1": Scene.dummy, "s3": Scene.glossy_dielectric, "s3env": Scene.glossy_dielectric}[scene_name]()
+    if scene_name == "s3env":
+        scene.env_map = EnvMap.sky(UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff")), 64, 64)
+    rel_mse, beyond3, z2, z2_clipped, z2_median = image_gate(gpu, libm_trig, scene, w, h, spp, max_depth)
+    print("image gate %s: rel_mse %.3g, |z|>3: %.4f, mean z^2 %.3f (clipped %.3f), median z^2 %.3f" % (scene_name, rel_mse, beyond3, z2, z2_clipped, z2_median))
+    assert rel_mse < 1e-3
+    if scene_name == "s3":
+        assert beyond3 < 0.03 and 0.5 < z2_clipped < 1.6 and z2_median < 0.8
+    else:
+        assert beyond3 < 0.01 and (0.8 if scene_name == "s1" else 0.5) < z2 < 1.25
 
 
 # ---- BASELINE sizes: size-independent properties -----------------------------------------------------
