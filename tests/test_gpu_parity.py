@@ -205,6 +205,27 @@ def test_traces_match_committed_golden(gpu):
 
 # ---- whole films -----------------------------------------------------------------------------------
 
+def test_traces_match_the_independent_numpy_restatement(gpu):
+    """The GPU against tests/golden/traces_s1_restated.npz: whole HwssNaive camera samples on the default scene computed by
+    tests/golden/restate_path.py in numpy float32 from the Rust text -- no C code (neither the oracle nor the kernels)
+    produced these numbers.  Bit for bit: wavelengths, primary ray, primitive and t of every bounce, draw count, radiance, XYZ."""
+    from iris_amd import Camera, Render, Scene
+    g = np.load(os.path.join(GOLD, "traces_s1_restated.npz"))
+    scene = Scene.dummy()
+    gpu.upload(scene)
+    w, h = int(g["width"]), int(g["height"])
+    r = Render(w, h, 64, scene, camera=Camera([float(v) for v in g["cam_pos"]], np.float32(w) / np.float32(h)))
+    assert np.array_equal(bits(r.camera.clip_to_world), bits(g["clip_to_world"]))
+    got = gpu.dbg_trace(r, g["xys"])
+    for i, t in enumerate(got):
+        n = int(g["n_hits"][i])
+        assert t.n_hits == n and t.draws == int(g["draws"][i]), i
+        assert list(t.hit_prim[:n]) == list(g["hit_prim"][i][:n])
+        assert np.array_equal(bits(list(t.hit_t[:n])), bits(g["hit_t"][i][:n]))
+        for name, val in (("hero", t.hero), ("ray_d", t.ray_d), ("radiance", t.radiance), ("xyz", t.xyz)):
+            assert np.array_equal(bits(list(val)), bits(g[name][i])), (name, i)
+
+
 def oracle_film(O, flat, w, h, spp, **kw):
     osc = O.OracleScene(flat)
     cam = O.camera_new([0, 0, 0], np.float32(w) / np.float32(h))

@@ -280,3 +280,32 @@ def test_sample_ranges_add_up(oracle):
     b, _, _, _ = sc.render(cam, oracle.make_params(16, 16, 8, spp_begin=3, spp_count=5), nthreads=2)
     assert np.allclose(a + b, full, rtol=1e-5, atol=1e-7)
     assert not np.array_equal(a, b)
+
+
+def test_oracle_matches_the_independent_numpy_restatement(oracle):
+    """tests/golden/traces_s1_restated.npz was produced by tests/golden/restate_path.py: a second restatement of a whole
+    HwssNaive camera sample on the default scene in numpy float32, written from the Rust text and sharing no code with
+    oracle/iris_oracle.c (Sobol points and sin/cos re-implemented from docs/SPEC.md).  Hero wavelengths, primary ray, every
+    bounce's primitive and t, the draw count, the radiance and the XYZ value agree bit for bit."""
+    g = np.load(os.path.join(GOLD, "traces_s1_restated.npz"))
+    from iris_amd import Scene
+    oracle.set_trig_mode(oracle.TRIG_IRIS)
+    try:
+        w, h = int(g["width"]), int(g["height"])
+        cam = oracle.camera_new([float(v) for v in g["cam_pos"]], np.float32(w) / np.float32(h))
+        assert np.array_equal(np.array(cam.clip_to_world, np.float32).view(np.uint32), g["clip_to_world"].reshape(-1).view(np.uint32))
+        sc = oracle.OracleScene(Scene.dummy().flatten())
+        p = oracle.make_params(w, h, 64)
+        n_bounces = 0
+        for i, (x, y, s) in enumerate(g["xys"]):
+            t = sc.trace(cam, p, int(x), int(y), int(s))
+            n = int(g["n_hits"][i])
+            assert t.n_hits == n and t.draws == int(g["draws"][i]), (i, x, y, s)
+            assert list(t.hit_prim[:n]) == list(g["hit_prim"][i][:n])
+            for name, got in (("hero", t.hero), ("ray_d", t.ray_d), ("radiance", t.radiance), ("xyz", t.xyz)):
+                assert np.array_equal(np.array(list(got), np.float32).view(np.uint32), g[name][i].view(np.uint32)), (name, i)
+            assert np.array_equal(np.array(list(t.hit_t[:n]), np.float32).view(np.uint32), g["hit_t"][i][:n].view(np.uint32)), i
+            n_bounces += n
+        assert n_bounces > 150 and float(g["radiance"].max()) > 0.5  # not a set of sky pixels (the light seen directly: 3.0 x balance_heuristic_1 = 0.75)
+    finally:
+        oracle.set_trig_mode(oracle.TRIG_LIBM)
