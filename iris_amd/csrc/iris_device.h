@@ -16,6 +16,7 @@
 
 #include "../../include/iris_hip.h"
 #include "iris_bvh_build.h"  // IRIS_BVH_STACK
+#include "iris_exact.h"
 
 #define IRIS_TABLE_QUAL __device__ const
 #include "tables/cie_cmf.inc"
@@ -46,8 +47,62 @@ IRIS_DEV int32_t f_as_i32(float f) {
     asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
     return r;
 }
-IRIS_DEV float rsqrt_exact(float x) { return __builtin_sqrtf(x); }  // correctly rounded (hipcc default for HIP)
 IRIS_DEV float fabs_(float x) { return __builtin_fabsf(x); }
+
+// ---------------------------------------------------------------- correctly rounded sqrt and division (iris_exact.h)
+// Every `/` and sqrt below is the IEEE result, as the reference computes it.  The compiler's general expansions cost 11
+// and 16 instructions; the sequences of iris_exact.h give the same bits in 3 (+3 per denominator) and 8 for operands
+// inside their domains (proved exhaustively on the GPU, tools/exact/verify_exact.hip).  The wrappers here test the domain
+// with a couple of integer instructions and fall back to the compiler's expansion for anything outside (lanes that do
+// so are rare enough never to be seen in a profile: zero-length vectors, grazing discriminants below 2^-96, NaNs).
+#ifndef IRIS_EXACT_FAST
+#define IRIS_EXACT_FAST 1   // 0: the compiler's expansions everywhere (the films must not change by a bit: tested)
+#endif
+// The domain tests are made wave-uniform: the fast sequence runs when EVERY active lane of the wave is inside the domain
+// (one scalar branch, no exec-mask bookkeeping); otherwise all of them take the compiler's expansion, which is right for
+// any operand.  Per-lane branches here cost more scalar instructions than the fast sequences save (measured).
+#define IRIS_ALL_LANES(cond) (__ballot(!(cond)) == 0ull)
+// lo <= x <= hi for POSITIVE finite bounds given as bit patterns; false for negative x, NaN and anything outside
+IRIS_DEV bool in_range_bits(float x, uint32_t lo_bits, uint32_t hi_bits) { return (__float_as_uint(x) - lo_bits) <= (hi_bits - lo_bits); }
+// every component is +-0 or at least 2^-100 in magnitude (the residual of the quotient stays exact)
+IRIS_DEV bool numerators_ok(float x, float y, float z) {
+    const uint32_t kx = exact::mag_key(x), ky = exact::mag_key(y), kz = exact::mag_key(z);
+    const uint32_t k = kx < ky ? (kx < kz ? kx : kz) : (ky < kz ? ky : kz);  // v_min3_u32
+    return k >= IRIS_EX_KEY(IRIS_EX_BITS_2M100);
+}
+// sqrt for any argument
+IRIS_DEV float sqrt_g(float x) {
+#if IRIS_EXACT_FAST
+    if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(x, IRIS_EX_BITS_2M96, IRIS_EX_BITS_2P126)), 1)) return exact::sqrt_fast_pos(x);
+#endif
+    return __builtin_sqrtf(x);
+}
+// sqrt for an argument that is +-0, NaN or in [2^-96, 2^126] BY CONSTRUCTION -- the call site says why.  The usual case:
+// max(1 - y, 0) with y >= 0 is 0 or at least 2^-24, and a difference of two floats the larger of which is at least 2^-24
+// is 0 or at least 2^-49.
+IRIS_DEV float sqrt_nz(float x) {
+#if IRIS_EXACT_FAST
+    return exact::sqrt_fast(x);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+IRIS_DEV float rsqrt_exact(float x) { return sqrt_g(x); }
+// 1 / d
+IRIS_DEV float rcp_g(float d) {
+#if IRIS_EXACT_FAST
+    if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(d, IRIS_EX_BITS_2M100, IRIS_EX_BITS_2P100)), 1)) return exact::rcp_refined(d);
+#endif
+    return 1.0f / d;
+}
+// x / PI_F
+IRIS_DEV float div_pi(float x) {
+#if IRIS_EXACT_FAST
+    if (__builtin_expect(IRIS_ALL_LANES(exact::mag_key(x) - IRIS_EX_KEY(IRIS_EX_BITS_2M100) <= IRIS_EX_KEY(IRIS_EX_BITS_2P100) - IRIS_EX_KEY(IRIS_EX_BITS_2M100) || x == 0.0f), 1))
+        return exact::div_pi_fast(x);
+#endif
+    return x / PI_F;
+}
 
 // ---------------------------------------------------------------- sin / cos (docs/SPEC.md)
 // f64 Cody-Waite reduction by pi/2 + fdlibm kernel polynomials, explicit fma chain,
@@ -116,16 +171,39 @@ IRIS_DEV V3 cross(V3 a, V3 b) {                                                 
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 IRIS_DEV float len_squared(V3 a) { return dot(a, a); }
-IRIS_DEV float len(V3 a) { return rsqrt_exact(len_squared(a)); }
-IRIS_DEV V3 normalize(V3 a) { return a / len(a); }  // vec3.rs:67-70: a true divide per component
+IRIS_DEV float len(V3 a) { return sqrt_g(len_squared(a)); }
+// a / d with one reciprocal for the three quotients; any d, any numerators (outside the proven domain: three divisions)
+IRIS_DEV V3 div3(V3 a, float d) {
+#if IRIS_EXACT_FAST
+    if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(d, IRIS_EX_BITS_2M60, IRIS_EX_BITS_2P60) && numerators_ok(a.x, a.y, a.z)), 1)) {
+        const exact::Recip y = exact::recip_for(d);
+        return v3(exact::div_by(a.x, d, y), exact::div_by(a.y, d, y), exact::div_by(a.z, d, y));
+    }
+#endif
+    return a / d;
+}
+// vec3.rs:67-70: self / self.len() -- a square root and a true divide per component
+IRIS_DEV V3 normalize(V3 a) {
+    const float l2 = len_squared(a);
+#if IRIS_EXACT_FAST
+    // 2^-96 <= |a|^2 <= 2^60, components zero or >= 2^-100: the length is in [2^-48, 2^30], the quotients in [2^-130.., 1] --
+    // no: a component of 2^-100 over a length of 2^30 would be denormal, hence the tighter upper bound 2^40 on |a|^2
+    if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(l2, IRIS_EX_BITS_2M96, 0x53800000u /* 2^40 */) && numerators_ok(a.x, a.y, a.z)), 1)) {
+        const float l = exact::sqrt_fast_pos(l2);
+        const exact::Recip y = exact::recip_for(l);
+        return v3(exact::div_by(a.x, l, y), exact::div_by(a.y, l, y), exact::div_by(a.z, l, y));
+    }
+#endif
+    return a / __builtin_sqrtf(l2);
+}
 IRIS_DEV float distance_squared(V3 a, V3 b) { return len_squared(a - b); }
-IRIS_DEV float distance(V3 a, V3 b) { return rsqrt_exact(distance_squared(a, b)); }
+IRIS_DEV float distance(V3 a, V3 b) { return sqrt_g(distance_squared(a, b)); }
 IRIS_DEV V3 face_forward(V3 s, V3 n) { return dot(s, n) >= 0.0f ? s : -s; }  // vec3.rs:105-111
 
 // vec3.rs:77-85 (divides by x^2+z^2, not its square root -- as written in the reference)
 IRIS_DEV void coordinate_system_from_unit(V3 s, V3 &v2, V3 &v3o) {
-    if (fabs_(s.x) > fabs_(s.y)) v2 = v3(-s.z, 0.0f, s.x) / (s.x * s.x + s.z * s.z);
-    else v2 = v3(0.0f, s.z, -s.y) / (s.y * s.y + s.z * s.z);
+    if (fabs_(s.x) > fabs_(s.y)) v2 = div3(v3(-s.z, 0.0f, s.x), s.x * s.x + s.z * s.z);
+    else v2 = div3(v3(0.0f, s.z, -s.y), s.y * s.y + s.z * s.z);
     v3o = cross(s, v2);
 }
 
@@ -133,7 +211,7 @@ IRIS_DEV void coordinate_system_from_unit(V3 s, V3 &v2, V3 &v3o) {
 IRIS_DEV float cos_theta(V3 w) { return w.z; }
 IRIS_DEV float cos_2_theta(V3 w) { return w.z * w.z; }
 IRIS_DEV float sin_2_theta(V3 w) { return rmax(1.0f - cos_2_theta(w), 0.0f); }
-IRIS_DEV float sin_theta(V3 w) { return rsqrt_exact(sin_2_theta(w)); }
+IRIS_DEV float sin_theta(V3 w) { return sqrt_nz(sin_2_theta(w)); }  // max(1 - z*z, 0)
 IRIS_DEV float tan_theta(V3 w) { return sin_theta(w) / cos_theta(w); }
 IRIS_DEV float tan_2_theta(V3 w) { return sin_2_theta(w) / cos_2_theta(w); }
 IRIS_DEV float cos_phi(V3 w) { float st = sin_theta(w); return st == 0.0f ? 0.0f : rclamp(w.x / st, -1.0f, 1.0f); }
@@ -191,10 +269,10 @@ IRIS_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {
     float ei, et, ci;
     if (cos_theta_i > 0.0f) { ei = eta_i; et = eta_t; ci = cos_theta_i; }
     else { ei = eta_t; et = eta_i; ci = fabs_(cos_theta_i); }
-    float sin_theta_i = rsqrt_exact(rmax(1.0f - ci * ci, 0.0f));
+    float sin_theta_i = sqrt_nz(rmax(1.0f - ci * ci, 0.0f));
     float sin_theta_t = ei / et * sin_theta_i;
     if (sin_theta_t >= 1.0f) return 1.0f;
-    float cos_theta_t = rsqrt_exact(rmax(1.0f - sin_theta_t * sin_theta_t, 0.0f));
+    float cos_theta_t = sqrt_nz(rmax(1.0f - sin_theta_t * sin_theta_t, 0.0f));
     float r_par = ((et * ci) - (ei * cos_theta_t)) / ((et * ci) + (ei * cos_theta_t));
     float r_perp = ((ei * ci) - (et * cos_theta_t)) / ((ei * ci) + (et * cos_theta_t));
     return (r_par * r_par + r_perp * r_perp) / 2.0f;
@@ -204,7 +282,7 @@ IRIS_DEV bool refract(V3 wi, V3 n, float eta, V3 &out) {  // mod.rs:61-72
     float sin_2_theta_i = rmax(1.0f - cos_theta_i * cos_theta_i, 0.0f);
     float sin_2_theta_t = eta * eta * sin_2_theta_i;
     if (sin_2_theta_t >= 1.0f) return false;
-    float cos_theta_t = rsqrt_exact(1.0f - sin_2_theta_t);
+    float cos_theta_t = sqrt_nz(1.0f - sin_2_theta_t);  // 0 <= sin_2_theta_t < 1 here (or NaN): the argument is at least 2^-24
     out = eta * (-wi) + n * (eta * cos_theta_i - cos_theta_t);
     return true;
 }
@@ -348,10 +426,10 @@ IRIS_DEV float gen_golden_ratio(const Sampler &s) {  // sampler.rs:65-71 (u32::M
 }
 
 // ---------------------------------------------------------------- warps (sampling/mod.rs), MIS (mis.rs)
-IRIS_DEV float pdf_cone(float cos_theta_max) { return 1.0f / (2.0f * PI_F * (1.0f - cos_theta_max)); }  // mod.rs:22-24
+IRIS_DEV float pdf_cone(float cos_theta_max) { return rcp_g(2.0f * PI_F * (1.0f - cos_theta_max)); }  // mod.rs:22-24
 IRIS_DEV V3 unit_sphere(float r1, float r2) {                                                              // mod.rs:26-31
     float z = 1.0f - 2.0f * r1;
-    float r = rsqrt_exact(rmax(1.0f - z * z, 0.0f));
+    float r = sqrt_nz(rmax(1.0f - z * z, 0.0f));
     float phi = 2.0f * PI_F * r2;
     float s, c;
     iris_sincos(phi, s, c);
@@ -368,7 +446,7 @@ IRIS_DEV V3 cosine_unit_hemisphere(float r1, float r2) {  // mod.rs:33-54
         iris_sincos(theta, s, c);
         x = r * c; y = r * s;
     }
-    float z = rsqrt_exact(rmax(1.0f - x * x - y * y, 0.0f));
+    float z = sqrt_nz(rmax(1.0f - x * x - y * y, 0.0f));  // (1 - x*x) is <= 0 or >= 2^-24; minus y*y: <= 0 or >= 2^-49
     return v3(x, y, z);
 }
 IRIS_DEV float balance_heuristic_1(F4 f) { return hero(f) / sum(f); }             // mis.rs:3-5
@@ -389,7 +467,7 @@ IRIS_DEV float spectrum_evaluate_single(const iris_spectrum &s, float lambda) {
     if (s.kind == IRIS_SPEC_CONSTANT) return s.c0;  // constant.rs:15-23
     // upsample.rs:18-24 / :35-41 -- explicit fused multiply-adds in the reference
     float x = __builtin_fmaf(__builtin_fmaf(s.c0, lambda, s.c1), lambda, s.c2);
-    float y = 1.0f / rsqrt_exact(__builtin_fmaf(x, x, 1.0f));
+    float y = rcp_g(rsqrt_exact(__builtin_fmaf(x, x, 1.0f)));
     float v = __builtin_fmaf(0.5f * x, y, 0.5f);
     return s.kind == IRIS_SPEC_UPSAMPLED ? v : s.hdr * v;
 }
@@ -468,11 +546,19 @@ IRIS_DEV V3 shading_to_world(const Hit &h, V3 s) {
 // the origin (both numerators <= 0: the sphere a bounce ray starts on, in every scan) costs no division at all.
 // Returns the first root > 0, or a value that is not > 0.
 IRIS_DEV bool a_is_unit(float a) { return a > 0.5f && a < 1.5f; }
-IRIS_DEV float first_positive_root(float half_b, float root, float a, bool a_unit) {
+// `ya`: exact::recip_for(a), formed once per ray (used only when a_unit: then a is inside its domain).
+IRIS_DEV float first_positive_root(float half_b, float root, float a, bool a_unit, exact::Recip ya) {
     const float n1 = -half_b - root, n2 = -half_b + root;
     if (a_unit) {
         const float num = n1 > 0.0f ? n1 : n2;
         float temp = -1.0f;
+#if IRIS_EXACT_FAST
+        // every lane's numerator is either not > 0 (no division at all) or inside the domain: 0.5 < a < 1.5 keeps the quotient there
+        if (__builtin_expect(IRIS_ALL_LANES(!(num > 0.0f) || in_range_bits(num, IRIS_EX_BITS_2M100, IRIS_EX_BITS_2P100)), 1)) {
+            if (num > 0.0f) temp = exact::div_by(num, a, ya);
+            return temp;
+        }
+#endif
         if (num > 0.0f) temp = num / a;
         return temp;
     }
@@ -481,13 +567,14 @@ IRIS_DEV float first_positive_root(float half_b, float root, float a, bool a_uni
     return temp;
 }
 IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
+    const exact::Recip ya = exact::recip_for(a);
     V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
     float half_b = dot(ray.d, oc);
     float c = len_squared(oc) - sp.w;
     float discrim = half_b * half_b - a * c;
     float t = -1.0f;
     if (discrim > 0.0f) {
-        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_is_unit(a));
+        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
         if (temp > 0.0f) t = temp;
     }
     return t;
@@ -495,13 +582,13 @@ IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
 // The same test inside a closest-hit scan: `if t < closest_t && t > 0 { closest = .. }` (scene.rs:123-126).
 // Almost every test of a long list ends at `discrim > 0` being false, so the bookkeeping of the closest
 // hit lives inside that branch and the common path is the discriminant alone.
-IRIS_DEV void sphere_test(float4 sp, const Ray &ray, float a, bool a_unit, int index, float &closest_t, int &closest) {
+IRIS_DEV void sphere_test(float4 sp, const Ray &ray, float a, bool a_unit, exact::Recip ya, int index, float &closest_t, int &closest) {
     V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
     float half_b = dot(ray.d, oc);
     float c = len_squared(oc) - sp.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {
-        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_unit);
+        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_unit, ya);
         if (temp > 0.0f && temp < closest_t) { closest_t = temp; closest = index; }
     }
 }
@@ -514,7 +601,7 @@ IRIS_DEV float4 stage_filler() { return make_float4(0.0f, 0.0f, 0.0f, -__builtin
 IRIS_DEV Hit sphere_frame(float4 sp, const Ray &ray, float t) {
     Hit h;
     h.point = ray.o + ray.d * t;
-    h.normal = (h.point - v3(sp.x, sp.y, sp.z)) / sp.w;
+    h.normal = div3(h.point - v3(sp.x, sp.y, sp.z), sp.w);
     h.tangeant = normalize(cross(v3(0.0f, 1.0f, 0.0f), h.normal));
     h.bitangeant = cross(h.normal, h.tangeant);
     h.back_face = dot(h.normal, ray.d) >= 0.0f;
@@ -550,6 +637,7 @@ IRIS_DEV uint32_t bvh_pop(const SphereStage &st, uint32_t sp) {
 template <uint32_t B>
 IRIS_DEV void scan_window(const float4 *win, uint32_t n, uint32_t base, const Ray &ray, float a, float &closest_t, int &closest) {
     const bool a_unit = a_is_unit(a);
+    const exact::Recip ya = exact::recip_for(a);  // one reciprocal of a = d.d per scan (sphere.rs:33 divides every root by it)
     for (uint32_t i = 0; i < n; i += B) {
         float4 sp[B];
 #pragma unroll
@@ -557,7 +645,7 @@ IRIS_DEV void scan_window(const float4 *win, uint32_t n, uint32_t base, const Ra
 #pragma unroll
         for (uint32_t k = 0; k < B; k++) {
             if (__builtin_amdgcn_readfirstlane(i + k) < __builtin_amdgcn_readfirstlane(n))
-                sphere_test(sp[k], ray, a, a_unit, (int)(base + i + k), closest_t, closest);
+                sphere_test(sp[k], ray, a, a_unit, ya, (int)(base + i + k), closest_t, closest);
         }
     }
 }
@@ -578,7 +666,7 @@ IRIS_DEV float box_entry(float4 lo, float4 hi, V3 o, V3 inv, float closest_t) {
     return (tmin <= tmax && tmin <= closest_t) ? tmin : __builtin_inff();  // inf: do not enter
 }
 // one leaf-ordered sphere, with the tie rule on the primitive index (visiting order is not index order)
-IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, float &closest_t, int &closest) {
+IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, exact::Recip ya, float &closest_t, int &closest) {
     const float4 sp4 = sc.bvh_spheres[slot];
     const int index = (int)sc.bvh_prim[slot];
     V3 oc = ray.o - v3(sp4.x, sp4.y, sp4.z);
@@ -586,7 +674,7 @@ IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray,
     float c = len_squared(oc) - sp4.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {  // sphere.rs:31-35, :53
-        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_is_unit(a));
+        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
         if (temp > 0.0f && (temp < closest_t || (temp == closest_t && index < closest))) { closest_t = temp; closest = index; }
     }
 }
@@ -599,14 +687,14 @@ IRIS_DEV uint32_t bvh_ref(float4 lo, float4 hi) { return __float_as_uint(lo.w) |
 // i.e. one hit at 0 < t < closest_t, or at t == closest_t with a lower index than `tie`?  (closest_t = the limit on entry,
 // unchanged on return; closest = the index of one such sphere, or -1.)  The limit culls boxes like a hit found at that
 // distance would, and the lane leaves the tree at the first such sphere: what a visibility test needs, and all it needs.
-IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, float limit, int tie, int &closest) {
+IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, exact::Recip ya, float limit, int tie, int &closest) {
     const float4 sp4 = sc.bvh_spheres[slot];
     V3 oc = ray.o - v3(sp4.x, sp4.y, sp4.z);
     float half_b = dot(ray.d, oc);
     float c = len_squared(oc) - sp4.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {  // sphere.rs:31-35, :53
-        float temp = first_positive_root(half_b, rsqrt_exact(discrim), a, a_is_unit(a));
+        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
         if (temp > 0.0f && (temp < limit || temp == limit)) {  // at the limit itself only spheres that would win the tie: index < tie
             const int index = (int)sc.bvh_prim[slot];
             if (temp < limit || index < tie) closest = index;
@@ -616,10 +704,11 @@ IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &
 template <bool ANY>
 IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests, int tie = 0x7fffffff) {
     const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const exact::Recip ya = exact::recip_for(a);
     uint32_t n_tests = sc.bvh_big_count;
     for (uint32_t k = 0; k < sc.bvh_big_count; k++) {
-        if (ANY) bvh_sphere_test_any(sc, sc.bvh_big_first + k, ray, a, closest_t, tie, closest);
-        else bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, closest_t, closest);
+        if (ANY) bvh_sphere_test_any(sc, sc.bvh_big_first + k, ray, a, ya, closest_t, tie, closest);
+        else bvh_sphere_test(sc, sc.bvh_big_first + k, ray, a, ya, closest_t, closest);
     }
     if (ANY && closest >= 0) { tests += n_tests; return; }
     const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
@@ -654,8 +743,8 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &
         if (!have) break;
         const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
         for (uint32_t k = 0; k < count; k++) {
-            if (ANY) bvh_sphere_test_any(sc, first + k, ray, a, closest_t, tie, closest);
-            else bvh_sphere_test(sc, first + k, ray, a, closest_t, closest);
+            if (ANY) bvh_sphere_test_any(sc, first + k, ray, a, ya, closest_t, tie, closest);
+            else bvh_sphere_test(sc, first + k, ray, a, ya, closest_t, closest);
         }
         n_tests += count;
         if (ANY && closest >= 0) {
@@ -721,17 +810,17 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
     coordinate_system_from_unit(wc, wc_x, wc_y);
     float sin_theta_max = radius / dc;
     float sin_theta_max_2 = sin_theta_max * sin_theta_max;
-    float cos_theta_max = rsqrt_exact(rmax(1.0f - sin_theta_max_2, 0.0f));
+    float cos_theta_max = sqrt_nz(rmax(1.0f - sin_theta_max_2, 0.0f));
     float sin_theta_2, cos_theta_;
     if (sin_theta_max_2 < 0.00068523f) {
         sin_theta_2 = sin_theta_max_2 * u0;
-        cos_theta_ = rsqrt_exact(rmax(1.0f - sin_theta_2, 0.0f));
+        cos_theta_ = sqrt_nz(rmax(1.0f - sin_theta_2, 0.0f));
     } else {
         cos_theta_ = (cos_theta_max - 1.0f) * u0 + 1.0f;
         sin_theta_2 = 1.0f - cos_theta_ * cos_theta_;
     }
-    float cos_alpha = sin_theta_2 / sin_theta_max + cos_theta_ * rsqrt_exact(rmax(1.0f - sin_theta_2 / sin_theta_max_2, 0.0f));
-    float sin_alpha = rsqrt_exact(rmax(1.0f - cos_alpha * cos_alpha, 0.0f));
+    float cos_alpha = sin_theta_2 / sin_theta_max + cos_theta_ * sqrt_nz(rmax(1.0f - sin_theta_2 / sin_theta_max_2, 0.0f));
+    float sin_alpha = sqrt_nz(rmax(1.0f - cos_alpha * cos_alpha, 0.0f));
     float phi = u1 * 2.0f * PI_F;
     float sphi, cphi;
     iris_sincos(phi, sphi, cphi);
@@ -759,7 +848,7 @@ IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &
         return 0.0f;
     }
     float sin_theta_max_2 = radius * radius / distance_squared(position, hit.point);
-    float cos_theta_max = rsqrt_exact(rmax(1.0f - sin_theta_max_2, 0.0f));
+    float cos_theta_max = sqrt_nz(rmax(1.0f - sin_theta_max_2, 0.0f));
     return pdf_cone(cos_theta_max);
 }
 
@@ -769,15 +858,15 @@ IRIS_DEV V3 ggx_sample(V3 wo_in, float ax, float ay, DrawRing ring, Sampler &smp
     float len_2 = wo.x * wo.x + wo.y * wo.y;
     V3 t1_v = len_2 > 0.0f ? v3(-wo.y, wo.x, 0.0f) / rsqrt_exact(len_2) : v3(1.0f, 0.0f, 0.0f);
     V3 t2_v = cross(wo, t1_v);
-    float r = rsqrt_exact(gen_0_1(ring, smp));
+    float r = sqrt_nz(gen_0_1(ring, smp));  // a draw is 0 or at least 2^-32
     float phi = 2.0f * PI_F * gen_0_1(ring, smp);
     float sphi, cphi;
     iris_sincos(phi, sphi, cphi);
     float t1 = r * cphi;
     float t2 = r * sphi;
     float s = 0.5f * (1.0f + wo.z);
-    t2 = (1.0f - s) * rsqrt_exact(1.0f - t1 * t1) + s * t2;
-    V3 nh = (t1 * t1_v + t2 * t2_v) + wo * rsqrt_exact(rmax(1.0f - t1 * t1 - t2 * t2, 0.0f));
+    t2 = (1.0f - s) * sqrt_nz(1.0f - t1 * t1) + s * t2;  // |t1| = r |cos| <= 1: the argument is 0 or at least 2^-24
+    V3 nh = (t1 * t1_v + t2 * t2_v) + wo * sqrt_nz(rmax(1.0f - t1 * t1 - t2 * t2, 0.0f));
     return normalize(v3(ax * nh.x, ay * nh.y, rmax(nh.z, 0.0f)));
 }
 IRIS_DEV float ggx_evaluate(V3 wh, float ax, float ay) {  // ggx.rs:35-43
@@ -787,7 +876,7 @@ IRIS_DEV float ggx_evaluate(V3 wh, float ax, float ay) {  // ggx.rs:35-43
     float ct = cos_theta(wh);
     float ct2 = ct * ct;
     float ope = 1.0f + e;
-    return 1.0f / (PI_F * ax * ay * (ct2 * ct2) * (ope * ope));
+    return rcp_g(PI_F * ax * ay * (ct2 * ct2) * (ope * ope));
 }
 IRIS_DEV float ggx_lambda(V3 w, float ax, float ay) {  // ggx.rs:45-55
     float tt = tan_theta(w);
@@ -796,8 +885,8 @@ IRIS_DEV float ggx_lambda(V3 w, float ax, float ay) {  // ggx.rs:45-55
     float a = alpha * fabs_(tt);
     return (-1.0f + rsqrt_exact(1.0f + a * a)) / 2.0f;
 }
-IRIS_DEV float ggx_g(V3 wo, V3 wh, float ax, float ay) { return 1.0f / (1.0f + ggx_lambda(wh, ax, ay) + ggx_lambda(wo, ax, ay)); }
-IRIS_DEV float ggx_g1(V3 w, float ax, float ay) { return 1.0f / (1.0f + ggx_lambda(w, ax, ay)); }
+IRIS_DEV float ggx_g(V3 wo, V3 wh, float ax, float ay) { return rcp_g(1.0f + ggx_lambda(wh, ax, ay) + ggx_lambda(wo, ax, ay)); }
+IRIS_DEV float ggx_g1(V3 w, float ax, float ay) { return rcp_g(1.0f + ggx_lambda(w, ax, ay)); }
 IRIS_DEV float ggx_pdf(V3 wo, V3 wh, float ax, float ay) {  // ggx.rs:61-64
     return ggx_evaluate(wh, ax, ay) * ggx_g1(wo, ax, ay) * fabs_(dot(wo, wh)) / fabs_(cos_theta(wo));
 }
@@ -810,7 +899,8 @@ IRIS_DEV V3 reflect(V3 wo, V3 n) { return (-wo) + (2.0f * dot(wo, n)) * n; }  //
 // division), so the three evaluations of a bounce cost a load instead of IEEE divisions.
 IRIS_DEV F4 lambertian_value(const SceneDev &sc, const iris_bsdf &b, F4 wl, bool mono) {
     if (mono || sc.spectra[b.spec_a].kind == IRIS_SPEC_CONSTANT) return splat(sc.spec_over_pi[b.spec_a]);
-    return spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / PI_F;
+    const F4 v = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono);
+    return f4(div_pi(v.v[0]), div_pi(v.v[1]), div_pi(v.v[2]), div_pi(v.v[3]));
 }
 IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl, bool mono) {  // microfacet.rs:33-57
     float cos_theta_o = fabs_(cos_theta(wo));
@@ -831,7 +921,7 @@ IRIS_DEV F4 bsdf_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, 
     return splat(0.0f);  // specular.rs:26-33, fresnel.rs:37-44
 }
 IRIS_DEV F4 bsdf_pdf(const iris_bsdf &b, V3 wi, V3 wo) {
-    if (b.kind == IRIS_BSDF_LAMBERTIAN) return splat(fabs_(cos_theta(wi)) / PI_F);  // lambertian.rs:33-35, mod.rs:56-59
+    if (b.kind == IRIS_BSDF_LAMBERTIAN) return splat(div_pi(fabs_(cos_theta(wi))));  // lambertian.rs:33-35, mod.rs:56-59
     if (b.kind == IRIS_BSDF_MICROFACET) {                                            // microfacet.rs:59-63
         V3 wh = normalize(wi + wo);
         return splat(ggx_pdf(wo, wh, b.p0, b.p1) / (4.0f * dot(wo, wh)));
@@ -849,7 +939,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         wi = same_hemisphere(wo, wi) ? wi : -wi;
         wi_out = wi;
         val_out = lambertian_value(sc, b, wl, mono);
-        pdf_out = splat(fabs_(cos_theta(wi)) / PI_F);
+        pdf_out = splat(div_pi(fabs_(cos_theta(wi))));
     } else if (b.kind == IRIS_BSDF_MICROFACET) {  // microfacet.rs:65-88
         V3 wh = ggx_sample(wo, b.p0, b.p1, ring, smp);
         V3 wi = reflect(wo, wh);
@@ -911,7 +1001,7 @@ IRIS_DEV uint32_t env_texel_coord(float t, uint32_t n) {
 // env_sample produces d.
 IRIS_DEV void env_eval(const SceneDev &sc, V3 d, F4 wl, F4 &le, float &pdf) {
     float s = (fabs_(d.x) + fabs_(d.y)) + fabs_(d.z);
-    V3 q = v3(d.x / s, d.y / s, d.z / s);
+    V3 q = div3(d, s);
     float u, v;
     if (q.y >= 0.0f) { u = q.x; v = q.z; }
     else { u = (1.0f - fabs_(q.z)) * env_sgn(q.x); v = (1.0f - fabs_(q.x)) * env_sgn(q.z); }
@@ -986,22 +1076,33 @@ struct FrameDev { uint32_t width, height, seed, max_depth, min_depth; };
 struct CamSample { uint32_t scramble; float hero_nm; V3 d; float u2, u3; };
 IRIS_DEV CamSample camera_sample(const CamDev &cam, const FrameDev &fr, SobolLds tab, uint32_t x, uint32_t y, uint32_t sample_index) {
     CamSample cs;
-    float cx = (((float)x + 0.5f) / (float)fr.width - 0.5f) * 2.0f;
-    float cy = (((float)y + 0.5f) / (float)fr.height - 0.5f) * -2.0f;
+    // Four quotients by the film's width and height per sample (tile.rs:134-138, :149-153).  1 <= W, H <= 2^31 (check_params); the
+    // numerators are x + 0.5 in [0.5, 2^31] and half a draw, which is 0 or at least 2^-33: all inside exact::div_by's domain.
+    const float fw = (float)fr.width, fh = (float)fr.height;
+#if IRIS_EXACT_FAST
+    const exact::Recip yw = exact::recip_for(fw), yh = exact::recip_for(fh);
+#define IRIS_DIV_W(n) exact::div_by((n), fw, yw)
+#define IRIS_DIV_H(n) exact::div_by((n), fh, yh)
+#else
+#define IRIS_DIV_W(n) ((n) / fw)
+#define IRIS_DIV_H(n) ((n) / fh)
+#endif
+    float cx = (IRIS_DIV_W((float)x + 0.5f) - 0.5f) * 2.0f;
+    float cy = (IRIS_DIV_H((float)y + 0.5f) - 0.5f) * -2.0f;
     Sampler smp = sampler_new(x, y, sample_index, fr.seed);
     cs.scramble = smp.scramble;
     cs.hero_nm = gen_golden_ratio(smp) * LAMBDA_RANGE_NM + LAMBDA_MIN_NM;  // wavelength.rs:26-28
     float u[4];
     sampler_set(tab, sample_index, 0u, smp.scramble, u);
     cs.u2 = u[2]; cs.u3 = u[3];
-    float j0 = 0.5f * u[0] / (float)fr.width;
-    float j1 = 0.5f * u[1] / (float)fr.height;
+    float j0 = IRIS_DIV_W(0.5f * u[0]);
+    float j1 = IRIS_DIV_H(0.5f * u[1]);
+#undef IRIS_DIV_W
+#undef IRIS_DIV_H
     float tx = cx + j0, ty = cy + j1, tz = 0.0f + 0.0f;
     const float *m = cam.m;  // matrix.rs:168-196
     float w = m[12] * tx + m[13] * ty + m[14] * tz + m[15];
-    V3 target = v3((m[0] * tx + m[1] * ty + m[2] * tz + m[3]) / w,
-                   (m[4] * tx + m[5] * ty + m[6] * tz + m[7]) / w,
-                   (m[8] * tx + m[9] * ty + m[10] * tz + m[11]) / w);
+    V3 target = div3(v3(m[0] * tx + m[1] * ty + m[2] * tz + m[3], m[4] * tx + m[5] * ty + m[6] * tz + m[7], m[8] * tx + m[9] * ty + m[10] * tz + m[11]), w);
     V3 origin = v3(cam.px, cam.py, cam.pz);
     cs.d = ray_new(origin, target - origin).d;
     return cs;

@@ -1115,6 +1115,10 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     if ((rc = check_params(c, p))) return rc;
     if ((rc = check_scene_for(c, p))) return rc;
     if (!cam || !d_out) return fail(c, IRIS_E_ARG, "camera or output is NULL");
+    for (int k = 0; k < 3; k++)
+        if (!(std::fabs(cam->position[k]) <= 0x1p60f)) return fail(c, IRIS_E_LIMIT, "camera position must be finite and at most 2^60 in magnitude");
+    for (int k = 0; k < 16; k++)
+        if (!std::isfinite(cam->clip_to_world[k])) return fail(c, IRIS_E_ARG, "camera matrix has a non-finite entry");
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t npix = p->width * p->height;
     c->stats = iris_stats{};
@@ -1416,6 +1420,10 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     if ((s->n_bsdfs && !s->bsdfs) || (s->n_spectra && !s->spectra) || (s->n_lights && !s->lights)) return fail(c, IRIS_E_ARG, "NULL table with non-zero count");
     // validate every index the kernels will follow, so that a malformed scene cannot fault the GPU
     for (uint32_t i = 0; i < s->n_prims; i++) {
+        // finite geometry of bounded size: squared distances (up to 2^123) then stay finite, which the intersection arithmetic relies on
+        const iris_sphere &q = s->spheres[i];
+        if (!(std::fabs(q.cx) <= 0x1p60f && std::fabs(q.cy) <= 0x1p60f && std::fabs(q.cz) <= 0x1p60f && std::fabs(q.r) <= 0x1p60f))
+            return fail(c, IRIS_E_LIMIT, "sphere " + std::to_string(i) + ": centre and radius must be finite and at most 2^60 in magnitude");
         if (s->prim_material[i] < -1 || s->prim_material[i] >= (int32_t)s->n_bsdfs) return fail(c, IRIS_E_ARG, "prim_material out of range");
         if (s->prim_light[i] < -1 || s->prim_light[i] >= (int32_t)s->n_lights) return fail(c, IRIS_E_ARG, "prim_light out of range");
     }
