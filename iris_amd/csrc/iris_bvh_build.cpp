@@ -36,11 +36,11 @@ void build_bvh_node(const iris_sphere *sp, std::vector<uint32_t> &order, uint32_
         box.add(c, std::fabs(s.r));
         cen.add(c, 0.0f);
     }
-    // Inflate: a hit point computed in f32 lies within a few ulps of the sphere, i.e. of the exact box; the pad is
-    // some thousand ulps of the largest coordinate, so no sphere that the list scan would report is ever culled.
-    float mag = 1.0f;
+    // Inflate by 16 ulps of the largest coordinate: covers the rounding of c +- r here and of the slab arithmetic on the device.
+    // What the f32 sphere test needs beyond the exact box is distance-dependent and added per ray and box (box_entry, iris_device.h).
+    float mag = 0.0f;
     for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(std::fabs(box.lo[k]), std::fabs(box.hi[k])));
-    const float pad = 1e-3f * mag;
+    const float pad = 1e-6f * mag + 1e-30f;
     const float lo[3] = {box.lo[0] - pad, box.lo[1] - pad, box.lo[2] - pad}, hi[3] = {box.hi[0] + pad, box.hi[1] + pad, box.hi[2] + pad};
     out.depth = std::max(out.depth, depth);
     if (end - begin <= out.leaf) {

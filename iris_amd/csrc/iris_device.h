@@ -656,10 +656,22 @@ IRIS_DEV void scan_window(const float4 *win, uint32_t n, uint32_t base, const Ra
 // decides which spheres are tested.  A subtree is skipped only if the ray misses its (host-inflated) box or
 // enters it strictly behind the closest hit so far, so a sphere that could win or tie is always visited;
 // visiting order is free, hence the explicit tie rule on the index.
+// How far outside a sphere a ray can pass and still be reported as a hit by the f32 arithmetic of sphere.rs:26-35 -- which the
+// list scan runs on every sphere, and the hierarchy must therefore never cull.  With u = 2^-24 and D = |o - c|: the computed
+// half_b^2 is off by at most 7u D^2, |oc|^2 - r^2 by 6u D^2, a*c by another 4u D^2, the difference rounds once more:
+// |error(discrim)| <= 18u D^2 < 1.1e-6 D^2.  A ray missing by m (discrim = r^2 - m^2 for a unit direction) can thus come out
+// positive only if m < sqrt(r^2 + 1.1e-6 D^2) <= r + 1.05e-3 D, and the same error moves a computed root by at most 1.05e-3 D
+// along the ray.  So every box is grown, per ray and per box, by 1.2e-3 x (an upper bound of the distance from the ray's origin
+// to any point of the box, hence to any centre inside it: the 1-norm of the per-axis farthest plane distances, which the slab
+// test has at hand): a sub-pixel sphere far away is "fat" for the reference's arithmetic, and is for the traversal too, while
+// boxes near the origin stay tight.  (The host adds 16 ulps of the coordinates for the rounding of the slab arithmetic itself.)
+#define IRIS_BVH_PAD 1.2e-3f
 IRIS_DEV float box_entry(float4 lo, float4 hi, V3 o, V3 inv, float closest_t) {
-    float tx0 = (lo.x - o.x) * inv.x, tx1 = (hi.x - o.x) * inv.x;
-    float ty0 = (lo.y - o.y) * inv.y, ty1 = (hi.y - o.y) * inv.y;
-    float tz0 = (lo.z - o.z) * inv.z, tz1 = (hi.z - o.z) * inv.z;
+    const float dx0 = lo.x - o.x, dx1 = hi.x - o.x, dy0 = lo.y - o.y, dy1 = hi.y - o.y, dz0 = lo.z - o.z, dz1 = hi.z - o.z;
+    const float pad = IRIS_BVH_PAD * ((__builtin_fmaxf(fabs_(dx0), fabs_(dx1)) + __builtin_fmaxf(fabs_(dy0), fabs_(dy1))) + __builtin_fmaxf(fabs_(dz0), fabs_(dz1)));
+    float tx0 = (dx0 - pad) * inv.x, tx1 = (dx1 + pad) * inv.x;
+    float ty0 = (dy0 - pad) * inv.y, ty1 = (dy1 + pad) * inv.y;
+    float tz0 = (dz0 - pad) * inv.z, tz1 = (dz1 + pad) * inv.z;
     // fminf / fmaxf ignore a NaN operand (0 * inf when the origin lies on a slab plane of an axis-parallel ray)
     float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fmaxf(__builtin_fminf(tz0, tz1), 0.0f));
     float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));

@@ -490,6 +490,41 @@ def test_many_spheres_scene_counters(gpu, gpu_list, iris_trig):
         assert g2.stats().kernel == 0 and g2.stats().sphere_tests == gh.sphere_tests
 
 
+def test_hierarchy_never_culls_what_the_f32_sphere_test_reports(gpu, gpu_list, iris_trig):
+    """Sub-pixel spheres far from the ray origin: the f32 discriminant of sphere.rs:30 errs by up to ~1e-6 |o - c|^2, so a
+    sphere of radius r reports hits for rays passing up to ~1e-3 |o - c| outside it -- more than r itself here -- and the
+    list scan, which is the reference, sees all of them.  The hierarchy's boxes are therefore grown per ray in proportion
+    to the distance (box_entry, iris_device.h); films, counters-independent: hierarchy == list scan == oracle, bit for bit,
+    for the camera at the origin, far outside the cloud, and inside it."""
+    from iris_amd import Camera, Render, Scene
+    from iris_amd.scene import ConstantSpectrum, LambertianBsdf, Sphere
+    rng = np.random.RandomState(4242)
+    scene = Scene()
+    scene.add_emissive_material(Sphere((0.0, 30.0, 60.0), 12.0), LambertianBsdf(ConstantSpectrum(0.5)), ConstantSpectrum(40.0))
+    scene.add_material(Sphere((0.0, -1001.5, 2.0), 1000.0), LambertianBsdf(ConstantSpectrum(0.8)))
+    for _ in range(400):
+        d = rng.uniform(10.0, 400.0)
+        ang = rng.uniform(-0.7, 0.7)
+        up = rng.uniform(-0.02, 0.5)
+        r = float(10.0 ** rng.uniform(-4.0, -2.0))
+        scene.add_material(Sphere((d * np.sin(ang), max(d * up - 1.4, -1.45), d * np.cos(ang)), r), LambertianBsdf(ConstantSpectrum(float(rng.uniform(0.2, 0.9)))))
+    flat_tree = gpu.upload(scene)
+    gpu_list.upload(scene)
+    assert len(flat_tree.spheres) >= 65
+    for pos in ((0.0, 0.0, 0.0), (0.0, 50.0, -900.0), (3.0, 4.0, 150.0)):
+        for w, h, spp in ((160, 120, 4), (31, 17, 16)):
+            r = Render(w, h, spp, scene, camera=Camera(pos, np.float32(w) / np.float32(h)))
+            tree = gpu.render_film(r)
+            assert gpu.stats().bvh_depth > 0
+            lst = gpu_list.render_film(r)
+            assert gpu_list.stats().bvh_depth == 0
+            assert np.array_equal(bits(tree), bits(lst)), (pos, w, h)
+    w, h, spp = 64, 48, 4
+    r = Render(w, h, spp, scene)
+    want, _ = oracle_film(iris_trig, flat_tree, w, h, spp)
+    assert np.array_equal(bits(gpu.render_film(r)), bits(want))
+
+
 def test_list_scan_films_of_long_lists(gpu_list, iris_trig):
     """The window-resident (600 spheres) and streamed (2500) list scans inside whole renders."""
     from iris_amd import Render
