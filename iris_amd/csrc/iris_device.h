@@ -713,9 +713,13 @@ IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &
         }
     }
 }
+// 1 / d per axis for the slab tests.  v_rcp_f32 (1 ulp): the boxes are grown by 1.2e-3 of the distance, which is some ten
+// thousand times the effect of that ulp; both traversals (bvh_closest, bvh_pooled) use the same value, so they enter the same
+// boxes and count the same sphere tests.
+IRIS_DEV V3 bvh_inv_dir(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 template <bool ANY>
 IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests, int tie = 0x7fffffff) {
-    const V3 inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const V3 inv = bvh_inv_dir(ray.d);
     const exact::Recip ya = exact::recip_for(a);
     uint32_t n_tests = sc.bvh_big_count;
     for (uint32_t k = 0; k < sc.bvh_big_count; k++) {
@@ -769,6 +773,224 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &
         }
     }
     tests += n_tests;
+}
+
+// ---- the same queries for a whole wave at once, with the rays detached from the lanes that own them ----
+// A ray's traversal takes between a handful and a few hundred steps, so a wave whose lanes each walk their own ray waits for
+// its slowest lane: config D ran at a quarter of its lanes.  Here the wave's rays -- the extension ray of every path that goes
+// on (closest hit) and the light-sample visibility query of every path that wants one (any hit up to a limit) -- live in a
+// small pool in LDS (two fixed slots per lane: its extension ray and its query), and lanes WALK rays independently of who
+// owns them: a lane that finishes a ray takes the next pending one, the result goes back to the slot, the owner reads it.
+// A pass does not wait for its slowest ray: when nothing is pending and fewer than IRIS_POOL_SUSPEND lanes are still walking,
+// the walkers park their rays (ray, node, stack) in global memory and the wave goes back to shading the paths whose rays are
+// done; the next pass resumes the parked rays among the new ones.  A path waits until BOTH of its rays are back, so the
+// additions to its radiance happen in the reference's order.  The lanes of a wave run in lockstep, so handing out slots
+// needs no atomics: ballots and bit counts.  Per ray the traversal is the one of bvh_closest, step for step (same boxes
+// entered, same spheres tested in the same order): results and test counts are the same bit for bit.
+#define IRIS_POOL_CAP 128u      // slots per wave: slot l = lane l's extension ray, slot 64 + l = its visibility query
+#define IRIS_POOL_FIELDS 8u     // o.xyz, d.xyz, limit / closest t so far, closest primitive so far (biased while the ray is out)
+#define IRIS_POOL_OUT 0x40000000  // field 7 holds (closest - IRIS_POOL_OUT) until the ray is done, then closest (>= -1)
+#ifndef IRIS_POOL_FETCH_MIN
+#define IRIS_POOL_FETCH_MIN 8u  // idle lanes that make a fetch worth its instructions (it runs for the idle lanes only)
+#endif
+#ifndef IRIS_POOL_SUSPEND
+#define IRIS_POOL_SUSPEND 16u   // a pass ends when nothing is pending and fewer lanes than this are walking (8..24 measure alike; 32 and more starve the shade phase)
+#endif
+#ifndef IRIS_POOL_MIN_ROUNDS
+#define IRIS_POOL_MIN_ROUNDS 6u // ... but not before this many rounds, so that parked rays move on in every pass
+#endif
+#define IRIS_WALK_WORDS (10u + IRIS_BVH_STACK)  // parked walker: o, d, closest t, closest, node reference, (slot, kind, stack depth), stack
+IRIS_DEV uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// position of the r-th set bit (r = 0: the lowest) of a 64-bit mask that has more than r bits set
+IRIS_DEV uint32_t nth_set_bit(unsigned long long mask, uint32_t r) {
+    const uint32_t lo = (uint32_t)mask, n_lo = (uint32_t)__popc(lo);
+    const bool upper = r >= n_lo;
+    uint32_t word = upper ? (uint32_t)(mask >> 32) : lo, base = upper ? 32u : 0u;
+    r -= upper ? n_lo : 0u;
+#pragma unroll
+    for (uint32_t shift = 16u; shift != 0u; shift >>= 1) {
+        const uint32_t c = (uint32_t)__popc(word & ((1u << shift) - 1u));
+        if (r >= c) { word >>= shift; r -= c; base += shift; }
+    }
+    return base;
+}
+IRIS_DEV void pool_sphere_test(const SceneDev &sc, uint32_t slot, V3 o, V3 d, float a, exact::Recip ya, bool any, float &cull_t, int &closest) {
+    const float4 sp4 = sc.bvh_spheres[slot];
+    V3 oc = o - v3(sp4.x, sp4.y, sp4.z);
+    float half_b = dot(d, oc);
+    float c = len_squared(oc) - sp4.w;
+    float discrim = half_b * half_b - a * c;
+    if (discrim > 0.0f) {  // sphere.rs:31-35, :53
+        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
+        if (temp > 0.0f) {
+            const int index = (int)sc.bvh_prim[slot];
+            if (any) { if (temp < cull_t || temp == cull_t) closest = index; }  // bvh_sphere_test_any with tie = none
+            else if (temp < cull_t || (temp == cull_t && index < closest)) { cull_t = temp; closest = index; }  // bvh_sphere_test
+        }
+    }
+}
+// The owner's part of a query, run with the whole wave busy: the spheres kept out of the tree (tested first, as bvh_closest
+// does), then the record.  A visibility query that one of those spheres already answers takes no slot: returns false, and
+// `closest` >= 0 says "occluded".
+IRIS_DEV bool pool_put(const SceneDev &sc, float *rec, uint32_t slot, const Ray &ray, bool any, float limit, int &closest, unsigned long long &tests) {
+    const float a = len_squared(ray.d);
+    const exact::Recip ya = exact::recip_for(a);
+    float cull_t = limit;
+    closest = -1;
+    for (uint32_t b = 0; b < sc.bvh_big_count; b++) pool_sphere_test(sc, sc.bvh_big_first + b, ray.o, ray.d, a, ya, any, cull_t, closest);
+    tests += sc.bvh_big_count;
+    if (any && closest >= 0) return false;
+    rec[0u * IRIS_POOL_CAP + slot] = ray.o.x; rec[1u * IRIS_POOL_CAP + slot] = ray.o.y; rec[2u * IRIS_POOL_CAP + slot] = ray.o.z;
+    rec[3u * IRIS_POOL_CAP + slot] = ray.d.x; rec[4u * IRIS_POOL_CAP + slot] = ray.d.y; rec[5u * IRIS_POOL_CAP + slot] = ray.d.z;
+    rec[6u * IRIS_POOL_CAP + slot] = cull_t;
+    rec[7u * IRIS_POOL_CAP + slot] = __int_as_float(closest - IRIS_POOL_OUT);
+    return true;
+}
+// Has the ray of `slot` come back?  (t, primitive) if so.
+IRIS_DEV bool pool_get(const float *rec, uint32_t slot, float &t, int &prim) {
+    const int v = __float_as_int(rec[7u * IRIS_POOL_CAP + slot]);
+    if (v < -1) return false;
+    prim = v;
+    t = rec[6u * IRIS_POOL_CAP + slot];
+    return true;
+}
+#ifdef IRIS_PHASE_TIMERS  // diagnostic build: passes, rays put, fetch rounds / lanes, inner rounds / lanes, leaf rounds / lanes
+__device__ unsigned long long g_pool_stats[8];
+#define IRIS_POOL_STAT(k, v) do { ps_[k] += (v); } while (0)
+#else
+#define IRIS_POOL_STAT(k, v) do { } while (0)
+#endif
+// One pass over the wave's pool.  pend_e / pend_s (wave-uniform, kept by the caller between passes): slots that hold a ray no
+// lane has taken yet; the caller has set the bits of the rays it has just put.  walking (per lane, kept by the caller): this lane
+// has a ray parked in `park` (its own IRIS_WALK_WORDS words of global memory, word k at park[k * park_stride]).
+IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *rec, uint32_t *park, size_t park_stride,
+                            unsigned long long &pend_e, unsigned long long &pend_s, bool &walking, unsigned long long &tests) {
+#ifdef IRIS_PHASE_TIMERS
+    unsigned long long ps_[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    IRIS_POOL_STAT(0, 1ull); IRIS_POOL_STAT(1, (unsigned long long)(__popcll(pend_e) + __popcll(pend_s)));
+#endif
+    bool have = false, any = false;
+    uint32_t my = 0u, ref = 0u, sp = 0u, n_tests = 0u;
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f), inv = v3(0.0f, 0.0f, 0.0f);
+    float a = 1.0f, cull_t = 0.0f;
+    exact::Recip ya = {1.0f};
+    int closest = -1;
+    // ---- resume: a lane that parked a ray at the end of the last pass takes it up again ----
+    if (walking) {
+        o = v3(__uint_as_float(park[0 * park_stride]), __uint_as_float(park[1 * park_stride]), __uint_as_float(park[2 * park_stride]));
+        d = v3(__uint_as_float(park[3 * park_stride]), __uint_as_float(park[4 * park_stride]), __uint_as_float(park[5 * park_stride]));
+        cull_t = __uint_as_float(park[6 * park_stride]);
+        closest = (int)park[7 * park_stride];
+        ref = park[8 * park_stride];
+        const uint32_t meta = park[9 * park_stride];
+        my = meta & 0xffu; any = (meta & 0x100u) != 0u; sp = meta >> 16;
+        for (uint32_t k = 0; k < sp; k++) bvh_push(st, k, park[(10u + k) * park_stride]);
+        a = len_squared(d);
+        ya = exact::recip_for(a);
+        inv = bvh_inv_dir(d);
+        have = true;
+        walking = false;
+    }
+    uint32_t rounds = 0u;
+    for (;;) {
+        const unsigned long long m_have = __ballot(have);
+        const uint32_t n_have = (uint32_t)__popcll(m_have), n_pe = (uint32_t)__popcll(pend_e), n_pend = n_pe + (uint32_t)__popcll(pend_s);
+        // ---- hand pending rays to the lanes that hold none: when enough of them are idle to pay for it, or nothing else is left to do ----
+        if (n_pend != 0u && (n_have == 0u || 64u - n_have >= IRIS_POOL_FETCH_MIN)) {
+            const uint32_t n_take = min(n_pend, 64u - n_have), r = lanes_below(~m_have);
+            IRIS_POOL_STAT(2, 1ull); IRIS_POOL_STAT(3, (unsigned long long)n_take);
+            if (!have && r < n_take) {
+                const uint32_t k = r < n_pe ? nth_set_bit(pend_e, r) : 64u + nth_set_bit(pend_s, r - n_pe);
+                my = k;
+                any = k >= 64u;
+                o = v3(rec[0u * IRIS_POOL_CAP + k], rec[1u * IRIS_POOL_CAP + k], rec[2u * IRIS_POOL_CAP + k]);
+                d = v3(rec[3u * IRIS_POOL_CAP + k], rec[4u * IRIS_POOL_CAP + k], rec[5u * IRIS_POOL_CAP + k]);
+                cull_t = rec[6u * IRIS_POOL_CAP + k];
+                closest = __float_as_int(rec[7u * IRIS_POOL_CAP + k]) + IRIS_POOL_OUT;
+                a = len_squared(d);  // sphere.rs:27
+                ya = exact::recip_for(a);
+                inv = bvh_inv_dir(d);
+                const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
+                ref = bvh_ref(root_lo, root_hi);
+                sp = 0u;
+                have = box_entry(root_lo, root_hi, o, inv, cull_t) < __builtin_inff();
+                if (!have) rec[7u * IRIS_POOL_CAP + k] = __int_as_float(closest);  // misses the tree: the big spheres' answer stands
+            }
+            // the first n_take pending slots are out: extension rays first, then queries, each in lane order
+            const uint32_t take_e = min(n_take, n_pe), take_s = n_take - take_e, me = lanes_below(~0ull);
+            const bool mine_e = ((pend_e >> me) & 1ull) != 0ull && (uint32_t)__popcll(pend_e & ((1ull << me) - 1ull)) < take_e;
+            const bool mine_s = ((pend_s >> me) & 1ull) != 0ull && (uint32_t)__popcll(pend_s & ((1ull << me) - 1ull)) < take_s;
+            pend_e &= ~__ballot(mine_e);
+            pend_s &= ~__ballot(mine_s);
+            continue;
+        }
+        if (n_have == 0u) break;  // nothing pending, nothing walking
+        if (n_pend == 0u && n_have < IRIS_POOL_SUSPEND && rounds >= IRIS_POOL_MIN_ROUNDS) break;  // park the stragglers
+        rounds++;
+        // ---- one kind of step per round, the kind more lanes are waiting for: inner nodes or leaves ----
+        const bool at_inner = have && (ref >> 29) == 0u;
+        const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
+        if (2u * n_inner >= n_have) {
+            IRIS_POOL_STAT(4, 1ull); IRIS_POOL_STAT(5, (unsigned long long)n_inner);
+            if (at_inner) {
+                const uint32_t first = ref & 0x1fffffffu;
+                const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
+                const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];
+                const float tl = box_entry(l0, l1, o, inv, cull_t), tr = box_entry(r0, r1, o, inv, cull_t);
+                const bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
+                if (hl || hr) {
+                    const bool left_first = hl && (!hr || tl <= tr);
+                    const uint32_t ref_l = bvh_ref(l0, l1), ref_r = bvh_ref(r0, r1);
+                    if (hl && hr) {
+                        bvh_push(st, sp, left_first ? ref_r : ref_l);
+                        sp++;
+                    }
+                    ref = left_first ? ref_l : ref_r;
+                } else if (sp != 0u) {
+                    sp--;
+                    ref = bvh_pop(st, sp);
+                } else {
+                    have = false;
+                }
+            }
+        } else if (have && !at_inner) {
+            IRIS_POOL_STAT(6, 1ull); IRIS_POOL_STAT(7, (unsigned long long)__popcll(__ballot(true)));
+            const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
+            for (uint32_t j = 0; j < count; j++) pool_sphere_test(sc, first + j, o, d, a, ya, any, cull_t, closest);
+            n_tests += count;
+            if (any && closest >= 0) {
+                have = false;
+            } else if (sp != 0u) {
+                sp--;
+                ref = bvh_pop(st, sp);
+            } else {
+                have = false;
+            }
+        }
+        if (!have && ((m_have >> lanes_below(~0ull)) & 1ull) != 0ull) {  // this lane held a ray at the top of the round and is done with it: result to its slot
+            rec[6u * IRIS_POOL_CAP + my] = cull_t;
+            rec[7u * IRIS_POOL_CAP + my] = __int_as_float(closest);
+        }
+    }
+    tests += n_tests;
+    // ---- park what is still walking ----
+    if (have) {
+        park[0 * park_stride] = __float_as_uint(o.x); park[1 * park_stride] = __float_as_uint(o.y); park[2 * park_stride] = __float_as_uint(o.z);
+        park[3 * park_stride] = __float_as_uint(d.x); park[4 * park_stride] = __float_as_uint(d.y); park[5 * park_stride] = __float_as_uint(d.z);
+        park[6 * park_stride] = __float_as_uint(cull_t);
+        park[7 * park_stride] = (uint32_t)closest;
+        park[8 * park_stride] = ref;
+        park[9 * park_stride] = my | (any ? 0x100u : 0u) | (sp << 16);
+        for (uint32_t k = 0; k < sp; k++) park[(10u + k) * park_stride] = bvh_pop(st, k);
+        walking = true;
+    }
+    __builtin_amdgcn_wave_barrier();
+#ifdef IRIS_PHASE_TIMERS
+    if (lanes_below(~0ull) == 0u)
+        for (int k = 0; k < 8; k++) atomicAdd(&g_pool_stats[k], ps_[k]);
+#endif
 }
 
 // Scene::intersection / ray_hits_point / ray_hits_object all reduce to this scan (scene.rs:116-166):
@@ -1177,9 +1399,33 @@ IRIS_DEV void path_miss(const SceneDev &sc, PathState &ps) {
     if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
     else ps.rad = ps.rad + ps.thr * le;
 }
-template <int INTEG, int CLS>
+// What shade_bounce<.., DEFER = true> leaves undone (Lambertian/constant class under a hierarchy, where the four wavelengths
+// carry one value): the light-sample visibility query of direct_light (hwss_naive.rs:115-123) is handed back to the caller, who
+// runs it in the wave's ray pool together with the extension rays (bvh_pooled) and then calls apply_deferred, which performs
+// the additions of hwss_naive.rs:131-133, :148-151, :155 and :61-62 in the reference's order on the values kept here.
+struct Deferred {
+    bool pending;      // there is a direct-light term to add (the hit has a material)
+    bool want1;        // the light sample passed the pre-checks: its visibility query is `ray1` up to `limit1`
+    bool has2;         // the BSDF-sampled ray reached the chosen light: `c2` counts
+    Ray ray1;
+    float limit1;
+    float c1, c2;      // the two MIS-weighted contributions (each the same for the four wavelengths)
+    float thr, weight; // throughput before this bounce's update, light pick weight
+};
+IRIS_DEV void apply_deferred(const Deferred &df, bool occluded1, PathState &ps) {
+    if (!df.pending) return;
+    const bool visible = df.want1 && !occluded1 && __builtin_inff() > df.limit1;  // scene.rs:147-148: closest_t > target_t - eps
+    F4 direct = splat(0.0f);
+    if (visible) direct = direct + splat(df.c1);
+    if (df.has2) direct = direct + splat(df.c2);
+    ps.rad = ps.rad + splat(df.thr) * (direct * df.weight);
+}
+template <int INTEG, int CLS, bool DEFER = false>
 IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, DrawRing ring, bool active,
-                           PathState &ps, int prim, float t, Counters &cnt) {
+                           PathState &ps, int prim, float t, Counters &cnt, Deferred *df = nullptr) {
+    static_assert(!DEFER || CLS == IRIS_CLS_LAMBERT_CONSTANT, "the deferred form keeps one value for the four wavelengths");
+    if (DEFER && active) { df->pending = false; df->want1 = false; df->has2 = false;  // (lanes that wait for their rays keep what they deferred)
+        df->limit1 = __builtin_inff(); df->c1 = 0.0f; df->c2 = 0.0f; df->thr = 0.0f; df->weight = 0.0f; }
     constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
     constexpr bool NAIVE = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_SWSS_NAIVE);
     // all draws of this bounce, generated for the whole wave at once: light pick 1 + light point 2 + BSDF 2 + BSDF 2 +
@@ -1265,7 +1511,21 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         float st1 = __builtin_inff();
         int sp1 = -1;
         bool visible_bvh = false;
-        if (st.bvh) {
+        if (DEFER) {
+            // the query and what it would add go back to the caller; nothing is traversed here (want1 implies active)
+            if (want1) {
+                df->want1 = true;
+                df->ray1 = shadow1;
+                cnt.rays++;
+                df->limit1 = len(light_pos - shadow1.o) / len(shadow1.d) - IRIS_RAY_EPSILON;
+                V3 shading_wi = world_to_shading(hit, shadow1.d);
+                F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl, MONO);
+                F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
+                float cos_t = fabs_(cos_theta(shading_wi));
+                float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : light_pdf / (hero(bsdf_pdfs) + light_pdf);
+                df->c1 = ((((mis_weight * light_emission) * bsdf_values) * cos_t) / light_pdf).v[0];
+            }
+        } else if (st.bvh) {
             // Scene::ray_hits_point and the map's visibility test (scene.rs:134-149) ask only whether the closest hit lies
             // beyond a limit: `closest_t > limit` with closest_t = inf when nothing is hit (the map: nothing hit at all,
             // i.e. limit = inf with equality allowed).  Under a hierarchy that needs no closest hit: it is false iff some
@@ -1281,7 +1541,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         } else {
             scan_closest(sc, st, want1, shadow1, st1, sp1, cnt.sphere_tests);  // scene.rs:134-149
         }
-        if (want1) {
+        if (want1 && !DEFER) {
             cnt.rays++;
             bool visible;
             if (st.bvh) {
@@ -1344,10 +1604,18 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 if (ENV && env_pick) env_eval(sc, shadow2.d, wl, light_emission, lpdf);
                 else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
                 float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : hero(bs_pdfs) / (hero(bs_pdfs) + lpdf);
-                direct = direct + (((mis_weight * light_emission) * bs_values) * bs_cos) / hero(bs_pdfs);
+                const F4 c2 = (((mis_weight * light_emission) * bs_values) * bs_cos) / hero(bs_pdfs);
+                if (DEFER) { df->has2 = true; df->c2 = c2.v[0]; }
+                else direct = direct + c2;
             }
         }
-        if (alive) ps.rad = ps.rad + ps.thr * (direct * light_pick_weight);  // hwss_naive.rs:61-62, :155
+        if (DEFER) {
+            if (alive) {
+                df->pending = true;
+                df->thr = ps.thr.v[0];
+                df->weight = light_pick_weight;
+            }
+        } else if (alive) ps.rad = ps.rad + ps.thr * (direct * light_pick_weight);  // hwss_naive.rs:61-62, :155
     }
 
     if (alive) {

@@ -83,6 +83,7 @@ struct WfArgs {
     uint32_t sphere_cap;      // LDS window, in spheres
     const unsigned char *sky;  // register kernel, short lists, no environment map: per pixel, 1 = no camera sample of this pixel
                                // can hit anything (k_sky_mask); nullptr: not used
+    uint32_t *park;           // pooled traversal (hierarchy + Lambertian/constant class): IRIS_WALK_WORDS words per lane for parked rays, word-major
     uint32_t *stack_hi;       // register kernel with a hierarchy: traversal-stack entries beyond the LDS ones, entry-major
     uint32_t stack_lds_n;     // traversal-stack entries per lane kept in LDS
     uint32_t *xq;             // register kernel, general classes: per wave, PQ_FIELDS x XQ_CAP words (see k_regwave)
@@ -340,7 +341,7 @@ k_wavefront(WfArgs a) {
 // The expensive shade phase therefore runs with (nearly) every lane busy as long as work is left, and the
 // camera-sample code never runs for a handful of lanes.  No other wave touches a wave's queue, so no
 // synchronisation is needed.
-enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u };
+enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u, LANE_FIN = 4u };  // FIN: the path has ended, its last visibility query is still out
 constexpr uint32_t XQ_CAP = 128;  // second queue (non-Lambertian primary hits), in global memory
 constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
 // BVH (compile-time): the scene has a hierarchy.  Traversal is bound by the latency of dependent L2 reads, so
@@ -348,16 +349,24 @@ constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz
 // level.  That variant therefore does without the Sobol nibble table (direction vectors come from the constant
 // table in global memory, bit by bit) and keeps a shorter primary-hit queue, which buys the third workgroup per
 // CU; the list-scan variant compiles no traversal code at all.
-template <bool BVH> struct PqGeom { static constexpr uint32_t CAP = BVH ? 80u : 104u; };  // < CAP - 63 queued when a generate phase starts, <= 64 added by it
+template <int CLS, bool BVH> struct PqGeom {  // < CAP - 63 queued when a generate phase starts, <= 64 added by it
+    static constexpr uint32_t CAP = BVH ? (CLS == IRIS_CLS_LAMBERT_CONSTANT ? 72u : 80u) : 104u;  // the pooled variant gives 1.4 KiB to its ray pool (three workgroups per CU)
+};
 
+// POOLED (hierarchy + Lambertian/constant class: the 10k-sphere configuration): the extension rays and the light-sample visibility
+// queries of a wave are traversed together by bvh_pooled, detached from the lanes that own them (iris_device.h); the shade phase
+// leaves its visibility query to the next loop top (shade_bounce<.., DEFER>), where the paths that ended wait for it as LANE_FIN.
+template <int CLS, bool BVH> struct PoolGeom { static constexpr bool ON = BVH && CLS == IRIS_CLS_LAMBERT_CONSTANT; };
 template <int INTEG, int CLS, bool BVH>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH && CLS == IRIS_CLS_LAMBERT_CONSTANT ? 4 : 3))) k_regwave(WfArgs a) {
-    constexpr uint32_t PQ_CAP = PqGeom<BVH>::CAP;
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_regwave(WfArgs a) {
+    constexpr bool POOLED = PoolGeom<CLS, BVH>::ON;
+    constexpr uint32_t PQ_CAP = PqGeom<CLS, BVH>::CAP;
     constexpr uint32_t PQ_LOW = PQ_CAP - 63u;  // generate while fewer records than this are queued
     extern __shared__ float4 sphere_win[];
     __shared__ uint2 sobol_tab[BVH ? 1 : IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
     __shared__ uint32_t primq[BLOCK / 64][PQ_FIELDS][PQ_CAP];
+    __shared__ float ray_pool[POOLED ? BLOCK / 64 : 1][POOLED ? IRIS_POOL_FIELDS * IRIS_POOL_CAP : 1];
     if (!BVH) stage_tables(sobol_tab);
     const SobolLds sobol_lds = BVH ? nullptr : sobol_tab;
     DrawRing ring = ring_lds + threadIdx.x;
@@ -409,9 +418,66 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
 #else
 #define IRIS_PHASE(k) do { } while (0)
 #endif
+    Deferred df = {};
+    // POOLED: what this lane has in the wave's ray pool (0 nothing, 1 to be put at the next loop top, 2 out, 3 extension ray back);
+    // the slots no walker has taken yet (wave-uniform); whether this lane, as a walker, has a ray parked in global memory
+    uint32_t own_e = 0u, own_s = 0u;
+    bool occluded1 = false, walking = false;
+    unsigned long long pend_e = 0ull, pend_s = 0ull;
     for (;;) {
         // ---- extend: the next ray of the paths that survived the last bounce ----
-        {
+        if (POOLED) {
+            float *const rec = ray_pool[threadIdx.x / 64];
+            const uint32_t me = lane_id();
+            // owners put the rays of the bounce just shaded: the spheres outside the tree are tested here, with the whole wave busy
+            {
+                const bool put_e = own_e == 1u;
+                int unused;
+                if (put_e) { (void)pool_put(a.sc, rec, me, ps.ray, false, __builtin_inff(), unused, cnt.sphere_tests); own_e = 2u; }
+                pend_e |= __ballot(put_e);
+                bool put_s = false;
+                if (own_s == 1u) {
+                    int occluder;
+                    put_s = pool_put(a.sc, rec, 64u + me, df.ray1, true, df.limit1, occluder, cnt.sphere_tests);
+                    own_s = put_s ? 2u : 0u;
+                    occluded1 = !put_s;
+                }
+                pend_s |= __ballot(put_s);
+                __builtin_amdgcn_wave_barrier();  // LDS operations of one wave complete in order: the walkers see these records
+            }
+            if ((pend_e | pend_s) != 0ull || __ballot(walking) != 0ull)
+                bvh_pool_pass(a.sc, st, rec, a.park + (size_t)blockIdx.x * BLOCK + threadIdx.x, (size_t)gridDim.x * BLOCK, pend_e, pend_s, walking, cnt.sphere_tests);
+            // owners: what has come back?
+            if (own_e == 2u) {
+                float t_new;
+                int prim_new;
+                if (pool_get(rec, me, t_new, prim_new)) { t = t_new; prim = prim_new; own_e = 3u; }
+            }
+            if (own_s == 2u) {
+                float t_unused;
+                int occluder;
+                if (pool_get(rec, 64u + me, t_unused, occluder)) { occluded1 = occluder >= 0; own_s = 0u; }
+            }
+            // a path moves on when both of its rays are back: first the direct light of the bounce just shaded (hwss_naive.rs:61-62),
+            // then the end of the path or its next hit
+            if ((lane_state == LANE_RAY || lane_state == LANE_FIN) && own_e != 2u && own_s != 2u) {
+                apply_deferred(df, occluded1, ps);
+                df.pending = false;
+                if (lane_state == LANE_FIN) {
+                    store_result(a, item, path_xyz<INTEG>(ps));
+                    lane_state = LANE_DEAD;
+                } else {
+                    cnt.rays++;
+                    own_e = 0u;
+                    if (prim >= 0) {
+                        lane_state = LANE_HIT;
+                    } else {  // `None => break` (hwss_naive.rs:41-44)
+                        store_result(a, item, path_xyz<INTEG>(ps));
+                        lane_state = LANE_DEAD;
+                    }
+                }
+            }
+        } else {
             const bool active = lane_state == LANE_RAY;
             if (__ballot(active) != 0ull) {
                 float t_new;
@@ -573,7 +639,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
         if (__ballot(active) == 0ull) {
             // Nothing to shade.  Without work left that is the end: a plain iteration is only chosen when nothing of
             // the second kind waits or plain work exists, so no lane holds a hit and both queues are empty.
-            if (!work_left) break;
+            // (POOLED: paths may still wait for rays that are out, walkers may hold parked rays: the next loop top moves them on.)
+            if (!work_left && (!POOLED || (__ballot(lane_state != LANE_DEAD) == 0ull && __ballot(walking) == 0ull))) break;
             continue;  // every camera sample of the last generate phase missed: generate again
         }
 #ifdef IRIS_PHASE_TIMERS
@@ -585,10 +652,13 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BVH 
             for (int kk = 1; kk <= 3; kk++) ph_kind[kk] += (unsigned long long)__popcll(__ballot(kd == kk));
             ph_mixed += 1ull; ph_mixed_lanes += (unsigned long long)__popcll(__ballot(active)); ph_mixed_x += (unsigned long long)__popcll(__ballot(lane_state == LANE_HITX)); }
 #endif
-        const bool cont = shade_bounce<INTEG, CLS>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt);
+        const bool cont = shade_bounce<INTEG, CLS, POOLED>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt, &df);
         if (active) {
+            if (POOLED) { own_e = cont ? 1u : 0u; own_s = (df.pending && df.want1) ? 1u : 0u; occluded1 = false; }
             if (cont) {
                 lane_state = LANE_RAY;
+            } else if (POOLED && df.pending) {
+                lane_state = LANE_FIN;  // its direct-light term is added once its visibility query is back, then the result is stored
             } else {
                 store_result(a, item, path_xyz<INTEG>(ps));
                 lane_state = LANE_DEAD;
@@ -903,7 +973,8 @@ struct iris_ctx {
     bool scene_is_lambert_constant = false;
     SceneDev sc = {};
     void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr, *d_spec_over_pi = nullptr, *d_prim_kind = nullptr;
-    uint32_t *d_xq = nullptr, *d_stack_hi = nullptr;
+    uint32_t *d_xq = nullptr, *d_stack_hi = nullptr, *d_park = nullptr;
+    size_t park_words = 0;
     unsigned char *d_sky = nullptr;
     size_t sky_cap = 0;
     unsigned long long *d_work_cursor = nullptr;  // register kernel: the launch's item counter
@@ -1107,7 +1178,7 @@ struct Workspace {
     float4 *film_acc = nullptr;        // running per-pixel sums between sample-range chunks (chunked renders only)
     unsigned char *sky = nullptr;
     unsigned long long *counters = nullptr, *work_cursor = nullptr;
-    uint32_t *xq = nullptr, *stack_hi = nullptr;
+    uint32_t *xq = nullptr, *stack_hi = nullptr, *park = nullptr;
 };
 
 int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *d_out, hipStream_t stream, bool no_alloc = false) {
@@ -1126,6 +1197,8 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     if (no_alloc && !reg) return fail(c, IRIS_E_LIMIT, "iris_render_device_noalloc serves the scenes of the register-resident kernel only (up to 64 spheres, or a hierarchy)");
     int64_t per_cu = reg ? c->reg_blocks_per_cu : c->blocks_per_cu;
     if (no_alloc) per_cu = std::min<int64_t>(per_cu, 4);  // a CU holds at most 4 of these workgroups; a smaller grid keeps the per-wave queues small
+    const bool pooled = reg && c->sc.n_bvh_nodes && c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;  // k_regwave<.., LAMBERT_CONSTANT, true>: the ray pool
+    if (pooled) per_cu = std::min<int64_t>(per_cu, 4);    // three are resident; every lane of the grid owns a parking area in global memory
     if (per_cu == 0) {
         const size_t dyn = (size_t)sphere_cap_for(c) * sizeof(float4);
         switch (p->integrator) {
@@ -1146,6 +1219,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     const bool use_sky = c->sky_mask && reg && !c->sc.n_bvh_nodes && c->sc.env_w == 0u && p->spp_count != 0u && p->max_depth != 0u;
     const size_t stack_hi_words = (reg && c->sc.n_bvh_nodes && c->bvh_depth > reg_stack_lds) ? (size_t)blocks * BLOCK * (c->bvh_depth - reg_stack_lds) : 0;
     const size_t xq_waves = (reg && c->scene_class == IRIS_CLS_GENERAL) ? (size_t)blocks * (BLOCK / 64) : 0;
+    const size_t park_words = pooled ? (size_t)blocks * BLOCK * IRIS_WALK_WORDS : 0;
     uint32_t spp_per_chunk;
     Workspace ws;
     if (no_alloc) {
@@ -1156,6 +1230,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         const size_t o_counters = carve(17 * sizeof(unsigned long long)), o_cursor = carve(sizeof(unsigned long long));
         const size_t o_sky = carve(use_sky ? npix : 0), o_xq = carve(xq_waves * PQ_FIELDS * XQ_CAP * sizeof(uint32_t));
         const size_t o_stack = carve(stack_hi_words * sizeof(uint32_t));
+        const size_t o_park = carve(park_words * sizeof(uint32_t));
         const size_t o_results = carve((size_t)p->spp_count * npix * sizeof(XyzResult));
         if (off > IRIS_NOALLOC_SCRATCH_BYTES || (uint64_t)p->spp_count * npix > (1ull << 31))
             return fail(c, IRIS_E_LIMIT, "iris_render_device_noalloc: this render needs " + std::to_string(off) + " bytes of workspace (12 per camera sample + " +
@@ -1167,6 +1242,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         ws.sky = base + o_sky;
         ws.xq = (uint32_t *)(base + o_xq);
         ws.stack_hi = (uint32_t *)(base + o_stack);
+        ws.park = (uint32_t *)(base + o_park);
         ws.results = (XyzResult *)(base + o_results);
         spp_per_chunk = std::max<uint32_t>(p->spp_count, 1u);
     } else {
@@ -1197,6 +1273,13 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
             if ((rc = dev_alloc(c, &c->d_stack_hi, stack_hi_words))) return rc;
             c->stack_hi_words = stack_hi_words;
         }
+        if (c->park_words < park_words) {  // parking areas of the pooled traversal
+            dev_free(c->d_park);
+            c->d_park = nullptr;
+            c->park_words = 0;
+            if ((rc = dev_alloc(c, &c->d_park, park_words))) return rc;
+            c->park_words = park_words;
+        }
         if (c->xq_waves < xq_waves) {  // second hit queue of the general classes
             dev_free(c->d_xq);
             c->d_xq = nullptr;
@@ -1218,6 +1301,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         ws.work_cursor = c->d_work_cursor;
         ws.xq = c->d_xq;
         ws.stack_hi = c->d_stack_hi;
+        ws.park = c->d_park;
     }
     HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 17 * sizeof(unsigned long long), stream));
     if (use_sky) {
@@ -1256,6 +1340,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.xq = ws.xq;
         a.sky = use_sky ? ws.sky : nullptr;
         a.stack_hi = ws.stack_hi;
+        a.park = ws.park;
         a.stack_lds_n = reg_stack_lds;
         if (reg && c->sc.n_bvh_nodes) a.sphere_cap = reg_stack_lds * BLOCK * sizeof(uint32_t) / sizeof(float4);  // LDS for the first levels only
         a.work_cursor = ws.work_cursor;
@@ -1303,6 +1388,13 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         std::fprintf(stderr, "[phase timers] shade iterations %llu, lanes holding a hit per iteration %.2f of 64\n", t[9], (double)t[8] / (double)std::max(1ull, t[9]));
         std::fprintf(stderr, "[phase timers] mixed iterations %llu: %.2f lanes shaded, %.2f of them of the second kind\n", t[11],
                      (double)t[12] / (double)std::max(1ull, t[11]), (double)t[13] / (double)std::max(1ull, t[11]));
+        {
+            unsigned long long g[8] = {};
+            (void)hipMemcpyFromSymbol(g, HIP_SYMBOL(g_pool_stats), sizeof g);
+            std::fprintf(stderr, "[pool] passes %llu rays/pass %.1f | fetch rounds/pass %.2f lanes/round %.1f | inner rounds/pass %.1f lanes/round %.1f | leaf rounds/pass %.1f lanes/round %.1f\n",
+                         g[0], (double)g[1] / std::max(1ull, g[0]), (double)g[2] / std::max(1ull, g[0]), (double)g[3] / std::max(1ull, g[2]),
+                         (double)g[4] / std::max(1ull, g[0]), (double)g[5] / std::max(1ull, g[4]), (double)g[6] / std::max(1ull, g[0]), (double)g[7] / std::max(1ull, g[6]));
+        }
         std::fprintf(stderr, "[phase timers] second-kind lanes per mixed iteration: microfacet %.2f specular %.2f fresnel %.2f\n", (double)t[14] / (double)std::max(1ull, t[11]),
                      (double)t[15] / (double)std::max(1ull, t[11]), (double)t[16] / (double)std::max(1ull, t[11]));
     }
@@ -1354,7 +1446,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
-    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_sky); dev_free(c->d_work_cursor);
+    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_park); dev_free(c->d_sky); dev_free(c->d_work_cursor);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
