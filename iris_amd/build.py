@@ -16,26 +16,34 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libiris_hip.so")
+# The opt-in relaxed-arithmetic build of the same sources (-DIRIS_RELAXED=1, iris_device.h): never the default, never what the
+# parity tests load; Context(relaxed=True) / bench.py's `relaxed` leg select it.
+LIB_RELAXED_PATH = os.path.join(LIB_DIR, "libiris_hip_relaxed.so")
 SOURCES = [os.path.join(CSRC, "iris_kernels.hip"), os.path.join(CSRC, "iris_host.cpp"), os.path.join(CSRC, "iris_bvh_build.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "iris_bvh_build.h"), os.path.join(CSRC, "tables", "cie_cmf.inc"),
+DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "iris_exact.h"), os.path.join(CSRC, "iris_bvh_build.h"), os.path.join(CSRC, "tables", "cie_cmf.inc"),
                   os.path.join(CSRC, "tables", "sobol_rev16.inc"), os.path.join(HERE, "..", "include", "iris_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def needs_build(path=LIB_PATH):
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
 def build(force=False, extra=()):
-    if force or needs_build():
-        os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = [HIPCC] + FLAGS + list(extra) + ["-o", LIB_PATH] + SOURCES
-        subprocess.check_call(cmd)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    jobs = []  # the two builds of the library run side by side (each is one long hipcc invocation)
+    if force or needs_build(LIB_PATH):
+        jobs.append(subprocess.Popen([HIPCC] + FLAGS + list(extra) + ["-o", LIB_PATH] + SOURCES))
+    if force or needs_build(LIB_RELAXED_PATH):
+        jobs.append(subprocess.Popen([HIPCC] + FLAGS + ["-DIRIS_RELAXED=1"] + list(extra) + ["-o", LIB_RELAXED_PATH] + SOURCES))
+    codes = [j.wait() for j in jobs]
+    if any(codes):
+        raise subprocess.CalledProcessError(max(codes), HIPCC)
     build_cli(force)
     return LIB_PATH
 

@@ -70,13 +70,38 @@ IRIS_DEV bool numerators_ok(float x, float y, float z) {
     const uint32_t k = kx < ky ? (kx < kz ? kx : kz) : (ky < kz ? ky : kz);  // v_min3_u32
     return k >= IRIS_EX_KEY(IRIS_EX_BITS_2M100);
 }
-// sqrt for any argument
-IRIS_DEV float sqrt_g(float x) {
+// Opt-in relaxed arithmetic (a separate build of the library, libiris_hip_relaxed.so: python -m iris_amd.build): the RADIOMETRIC
+// code -- light sampling, BSDFs, MIS weights, spectra, the environment map, i.e. everything between a hit and the next ray --
+// uses v_rcp / v_sqrt / v_rsq results (1 ulp) instead of correctly rounded quotients and roots, and lets the compiler contract
+// a * b + c.  The camera sample (pixel, wavelength, first ray), the sampler and every sphere and box test keep the exact
+// arithmetic, so a given ray still finds the same hit at the same distance, bit for bit.  The film is then no longer the
+// reference's bit for bit; it is held to north_star's statistical gate instead (tests/test_gpu_relaxed.py).
+#ifndef IRIS_RELAXED
+#define IRIS_RELAXED 0
+#endif
+#if IRIS_RELAXED
+#define IRIS_RADIOMETRIC_BEGIN _Pragma("clang fp contract(fast)")
+#define IRIS_RADIOMETRIC_END _Pragma("clang fp contract(off)")
+#else
+#define IRIS_RADIOMETRIC_BEGIN
+#define IRIS_RADIOMETRIC_END
+#endif
+// sqrt for any argument, always the IEEE result (sphere tests, camera)
+IRIS_DEV float sqrt_x(float x) {
 #if IRIS_EXACT_FAST
     if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(x, IRIS_EX_BITS_2M96, IRIS_EX_BITS_2P126)), 1)) return exact::sqrt_fast_pos(x);
 #endif
     return __builtin_sqrtf(x);
 }
+#if IRIS_RELAXED
+IRIS_DEV float sqrt_g(float x) { return __builtin_amdgcn_sqrtf(x); }
+IRIS_DEV float sqrt_nz(float x) { return __builtin_amdgcn_sqrtf(x); }
+IRIS_DEV float rcp_g(float d) { return __builtin_amdgcn_rcpf(d); }
+IRIS_DEV float div_pi(float x) { return x * IRIS_EX_INV_PI; }
+IRIS_DEV float fdiv(float n, float d) { return n * __builtin_amdgcn_rcpf(d); }
+#else
+// sqrt for any argument (radiometric code: relaxed in the relaxed build)
+IRIS_DEV float sqrt_g(float x) { return sqrt_x(x); }
 // sqrt for an argument that is +-0, NaN or in [2^-96, 2^126] BY CONSTRUCTION -- the call site says why.  The usual case:
 // max(1 - y, 0) with y >= 0 is 0 or at least 2^-24, and a difference of two floats the larger of which is at least 2^-24
 // is 0 or at least 2^-49.
@@ -87,7 +112,6 @@ IRIS_DEV float sqrt_nz(float x) {
     return __builtin_sqrtf(x);
 #endif
 }
-IRIS_DEV float rsqrt_exact(float x) { return sqrt_g(x); }
 // 1 / d
 IRIS_DEV float rcp_g(float d) {
 #if IRIS_EXACT_FAST
@@ -103,6 +127,10 @@ IRIS_DEV float div_pi(float x) {
 #endif
     return x / PI_F;
 }
+// n / d in the radiometric code (one correctly rounded division; the relaxed build multiplies by v_rcp)
+IRIS_DEV float fdiv(float n, float d) { return n / d; }
+#endif
+IRIS_DEV float rsqrt_exact(float x) { return sqrt_g(x); }
 
 // ---------------------------------------------------------------- sin / cos (docs/SPEC.md)
 // f64 Cody-Waite reduction by pi/2 + fdlibm kernel polynomials, explicit fma chain,
@@ -173,7 +201,7 @@ IRIS_DEV V3 cross(V3 a, V3 b) {                                                 
 IRIS_DEV float len_squared(V3 a) { return dot(a, a); }
 IRIS_DEV float len(V3 a) { return sqrt_g(len_squared(a)); }
 // a / d with one reciprocal for the three quotients; any d, any numerators (outside the proven domain: three divisions)
-IRIS_DEV V3 div3(V3 a, float d) {
+IRIS_DEV V3 div3_x(V3 a, float d) {
 #if IRIS_EXACT_FAST
     if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(d, IRIS_EX_BITS_2M60, IRIS_EX_BITS_2P60) && numerators_ok(a.x, a.y, a.z)), 1)) {
         const exact::Recip y = exact::recip_for(d);
@@ -183,7 +211,7 @@ IRIS_DEV V3 div3(V3 a, float d) {
     return a / d;
 }
 // vec3.rs:67-70: self / self.len() -- a square root and a true divide per component
-IRIS_DEV V3 normalize(V3 a) {
+IRIS_DEV V3 normalize_x(V3 a) {
     const float l2 = len_squared(a);
 #if IRIS_EXACT_FAST
     // 2^-96 <= |a|^2 <= 2^60, components zero or >= 2^-100: the length is in [2^-48, 2^30], the quotients in [2^-130.., 1] --
@@ -196,6 +224,14 @@ IRIS_DEV V3 normalize(V3 a) {
 #endif
     return a / __builtin_sqrtf(l2);
 }
+// the same two in the radiometric code
+#if IRIS_RELAXED
+IRIS_DEV V3 div3(V3 a, float d) { return a * __builtin_amdgcn_rcpf(d); }
+IRIS_DEV V3 normalize(V3 a) { return a * __builtin_amdgcn_rsqf(len_squared(a)); }
+#else
+IRIS_DEV V3 div3(V3 a, float d) { return div3_x(a, d); }
+IRIS_DEV V3 normalize(V3 a) { return normalize_x(a); }
+#endif
 IRIS_DEV float distance_squared(V3 a, V3 b) { return len_squared(a - b); }
 IRIS_DEV float distance(V3 a, V3 b) { return sqrt_g(distance_squared(a, b)); }
 IRIS_DEV V3 face_forward(V3 s, V3 n) { return dot(s, n) >= 0.0f ? s : -s; }  // vec3.rs:105-111
@@ -207,15 +243,16 @@ IRIS_DEV void coordinate_system_from_unit(V3 s, V3 &v2, V3 &v3o) {
     v3o = cross(s, v2);
 }
 
+IRIS_RADIOMETRIC_BEGIN
 // shading-space trigonometry, vec3.rs:301-355
 IRIS_DEV float cos_theta(V3 w) { return w.z; }
 IRIS_DEV float cos_2_theta(V3 w) { return w.z * w.z; }
 IRIS_DEV float sin_2_theta(V3 w) { return rmax(1.0f - cos_2_theta(w), 0.0f); }
 IRIS_DEV float sin_theta(V3 w) { return sqrt_nz(sin_2_theta(w)); }  // max(1 - z*z, 0)
-IRIS_DEV float tan_theta(V3 w) { return sin_theta(w) / cos_theta(w); }
-IRIS_DEV float tan_2_theta(V3 w) { return sin_2_theta(w) / cos_2_theta(w); }
-IRIS_DEV float cos_phi(V3 w) { float st = sin_theta(w); return st == 0.0f ? 0.0f : rclamp(w.x / st, -1.0f, 1.0f); }
-IRIS_DEV float sin_phi(V3 w) { float st = sin_theta(w); return st == 0.0f ? 0.0f : rclamp(w.y / st, -1.0f, 1.0f); }
+IRIS_DEV float tan_theta(V3 w) { return fdiv(sin_theta(w), cos_theta(w)); }
+IRIS_DEV float tan_2_theta(V3 w) { return fdiv(sin_2_theta(w), cos_2_theta(w)); }
+IRIS_DEV float cos_phi(V3 w) { float st = sin_theta(w); return st == 0.0f ? 0.0f : rclamp(fdiv(w.x, st), -1.0f, 1.0f); }
+IRIS_DEV float sin_phi(V3 w) { float st = sin_theta(w); return st == 0.0f ? 0.0f : rclamp(fdiv(w.y, st), -1.0f, 1.0f); }
 IRIS_DEV float cos_2_phi(V3 w) { float c = cos_phi(w); return c * c; }
 IRIS_DEV float sin_2_phi(V3 w) { float s = sin_phi(w); return s * s; }
 IRIS_DEV bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }
@@ -226,7 +263,7 @@ IRIS_DEV F4 splat(float x) { return f4(x, x, x, x); }
     IRIS_DEV F4 name(F4 a, F4 b) { F4 r; _Pragma("unroll") for (int i = 0; i < 4; i++) { float x = a.v[i], y = b.v[i]; r.v[i] = (expr); } return r; }
 IRIS_F4_OP(operator+, x + y)
 IRIS_F4_OP(operator*, x * y)
-IRIS_F4_OP(operator/, x / y)
+IRIS_F4_OP(operator/, fdiv(x, y))
 IRIS_DEV F4 operator*(F4 a, float s) { return a * splat(s); }
 IRIS_DEV F4 operator*(float s, F4 a) { return splat(s) * a; }
 IRIS_DEV F4 operator/(F4 a, float s) { return a / splat(s); }
@@ -236,6 +273,7 @@ IRIS_DEV float hero(F4 a) { return a.v[0]; }
 // vec4.rs:55-57: f32x4::reduce_sum is the ordered reduction starting from -0.0
 IRIS_DEV float sum(F4 a) { return ((((-0.0f) + a.v[0]) + a.v[1]) + a.v[2]) + a.v[3]; }
 
+IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- rays (math/ray.rs)
 #define IRIS_RAY_EPSILON 0.001f  // ray.rs:5
 struct Ray { V3 o, d; };
@@ -263,6 +301,7 @@ IRIS_DEV Ray ray_spawn_to(V3 o, V3 p, V3 normal) {  // ray.rs:34-45 (direction f
     return r;
 }
 
+IRIS_RADIOMETRIC_BEGIN
 // ---------------------------------------------------------------- math/mod.rs
 IRIS_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {  // mod.rs:35-59
     cos_theta_i = rclamp(cos_theta_i, -1.0f, 1.0f);
@@ -270,11 +309,11 @@ IRIS_DEV float fresnel_dielectric(float cos_theta_i, float eta_i, float eta_t) {
     if (cos_theta_i > 0.0f) { ei = eta_i; et = eta_t; ci = cos_theta_i; }
     else { ei = eta_t; et = eta_i; ci = fabs_(cos_theta_i); }
     float sin_theta_i = sqrt_nz(rmax(1.0f - ci * ci, 0.0f));
-    float sin_theta_t = ei / et * sin_theta_i;
+    float sin_theta_t = fdiv(ei, et) * sin_theta_i;
     if (sin_theta_t >= 1.0f) return 1.0f;
     float cos_theta_t = sqrt_nz(rmax(1.0f - sin_theta_t * sin_theta_t, 0.0f));
-    float r_par = ((et * ci) - (ei * cos_theta_t)) / ((et * ci) + (ei * cos_theta_t));
-    float r_perp = ((ei * ci) - (et * cos_theta_t)) / ((ei * ci) + (et * cos_theta_t));
+    float r_par = fdiv((et * ci) - (ei * cos_theta_t), (et * ci) + (ei * cos_theta_t));
+    float r_perp = fdiv((ei * ci) - (et * cos_theta_t), (ei * ci) + (et * cos_theta_t));
     return (r_par * r_par + r_perp * r_perp) / 2.0f;
 }
 IRIS_DEV bool refract(V3 wi, V3 n, float eta, V3 &out) {  // mod.rs:61-72
@@ -287,6 +326,7 @@ IRIS_DEV bool refract(V3 wi, V3 n, float eta, V3 &out) {  // mod.rs:61-72
     return true;
 }
 
+IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- sampler (sampling/sampler.rs)
 IRIS_DEV uint32_t hash_u32(uint32_t n, uint32_t seed) {  // sampler.rs:74-83
     uint32_t h = n;
@@ -425,6 +465,7 @@ IRIS_DEV float gen_golden_ratio(const Sampler &s) {  // sampler.rs:65-71 (u32::M
     return (float)u / 4294967296.0f;
 }
 
+IRIS_RADIOMETRIC_BEGIN
 // ---------------------------------------------------------------- warps (sampling/mod.rs), MIS (mis.rs)
 IRIS_DEV float pdf_cone(float cos_theta_max) { return rcp_g(2.0f * PI_F * (1.0f - cos_theta_max)); }  // mod.rs:22-24
 IRIS_DEV V3 unit_sphere(float r1, float r2) {                                                              // mod.rs:26-31
@@ -440,8 +481,8 @@ IRIS_DEV V3 cosine_unit_hemisphere(float r1, float r2) {  // mod.rs:33-54
     float x = 0.0f, y = 0.0f;
     if (!(x_off == 0.0f && y_off == 0.0f)) {
         float r, theta;
-        if (fabs_(x_off) > fabs_(y_off)) { r = x_off; theta = PI_F / 4.0f * (y_off / x_off); }
-        else { r = y_off; theta = (PI_F / 2.0f) - (PI_F / 4.0f) * (x_off / y_off); }
+        if (fabs_(x_off) > fabs_(y_off)) { r = x_off; theta = PI_F / 4.0f * fdiv(y_off, x_off); }
+        else { r = y_off; theta = (PI_F / 2.0f) - (PI_F / 4.0f) * fdiv(x_off, y_off); }
         float s, c;
         iris_sincos(theta, s, c);
         x = r * c; y = r * s;
@@ -449,9 +490,10 @@ IRIS_DEV V3 cosine_unit_hemisphere(float r1, float r2) {  // mod.rs:33-54
     float z = sqrt_nz(rmax(1.0f - x * x - y * y, 0.0f));  // (1 - x*x) is <= 0 or >= 2^-24; minus y*y: <= 0 or >= 2^-49
     return v3(x, y, z);
 }
-IRIS_DEV float balance_heuristic_1(F4 f) { return hero(f) / sum(f); }             // mis.rs:3-5
-IRIS_DEV float balance_heuristic_2(F4 f, F4 g) { return hero(f) / sum(f + g); }  // mis.rs:8-10
+IRIS_DEV float balance_heuristic_1(F4 f) { return fdiv(hero(f), sum(f)); }             // mis.rs:3-5
+IRIS_DEV float balance_heuristic_2(F4 f, F4 g) { return fdiv(hero(f), sum(f + g)); }  // mis.rs:8-10
 
+IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- spectra, colour
 #define LAMBDA_MIN_NM 360.0f
 #define LAMBDA_MAX_NM 830.0f
@@ -463,6 +505,7 @@ IRIS_DEV float rotate_n(float h, uint32_t n) {  // wavelength.rs:55-64
 }
 IRIS_DEV F4 wavelength_new(float h) { return f4(h, rotate_n(h, 1), rotate_n(h, 2), rotate_n(h, 3)); }  // wavelength.rs:14-24
 
+IRIS_RADIOMETRIC_BEGIN
 IRIS_DEV float spectrum_evaluate_single(const iris_spectrum &s, float lambda) {
     if (s.kind == IRIS_SPEC_CONSTANT) return s.c0;  // constant.rs:15-23
     // upsample.rs:18-24 / :35-41 -- explicit fused multiply-adds in the reference
@@ -495,6 +538,7 @@ IRIS_DEV V3 spectral_to_xyz(F4 value, F4 wl) {
     return v3(((X[0] + X[1]) + X[2]) + X[3], ((Y[0] + Y[1]) + Y[2]) + Y[3], ((Z[0] + Z[1]) + Z[2]) + Z[3]);
 }
 
+IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- scene on the device
 struct SceneDev {
     const float4 *spheres;      // (cx, cy, cz, r), primitive order
@@ -574,7 +618,7 @@ IRIS_DEV float sphere_hit_t(float4 sp, const Ray &ray, float a) {
     float discrim = half_b * half_b - a * c;
     float t = -1.0f;
     if (discrim > 0.0f) {
-        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
+        float temp = first_positive_root(half_b, sqrt_x(discrim), a, a_is_unit(a), ya);
         if (temp > 0.0f) t = temp;
     }
     return t;
@@ -588,7 +632,7 @@ IRIS_DEV void sphere_test(float4 sp, const Ray &ray, float a, bool a_unit, exact
     float c = len_squared(oc) - sp.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {
-        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_unit, ya);
+        float temp = first_positive_root(half_b, sqrt_x(discrim), a, a_unit, ya);
         if (temp > 0.0f && temp < closest_t) { closest_t = temp; closest = index; }
     }
 }
@@ -686,7 +730,7 @@ IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray,
     float c = len_squared(oc) - sp4.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {  // sphere.rs:31-35, :53
-        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
+        float temp = first_positive_root(half_b, sqrt_x(discrim), a, a_is_unit(a), ya);
         if (temp > 0.0f && (temp < closest_t || (temp == closest_t && index < closest))) { closest_t = temp; closest = index; }
     }
 }
@@ -706,7 +750,7 @@ IRIS_DEV void bvh_sphere_test_any(const SceneDev &sc, uint32_t slot, const Ray &
     float c = len_squared(oc) - sp4.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {  // sphere.rs:31-35, :53
-        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
+        float temp = first_positive_root(half_b, sqrt_x(discrim), a, a_is_unit(a), ya);
         if (temp > 0.0f && (temp < limit || temp == limit)) {  // at the limit itself only spheres that would win the tie: index < tie
             const int index = (int)sc.bvh_prim[slot];
             if (temp < limit || index < tie) closest = index;
@@ -823,7 +867,7 @@ IRIS_DEV void pool_sphere_test(const SceneDev &sc, uint32_t slot, V3 o, V3 d, fl
     float c = len_squared(oc) - sp4.w;
     float discrim = half_b * half_b - a * c;
     if (discrim > 0.0f) {  // sphere.rs:31-35, :53
-        float temp = first_positive_root(half_b, sqrt_g(discrim), a, a_is_unit(a), ya);
+        float temp = first_positive_root(half_b, sqrt_x(discrim), a, a_is_unit(a), ya);
         if (temp > 0.0f) {
             const int index = (int)sc.bvh_prim[slot];
             if (any) { if (temp < cull_t || temp == cull_t) closest = index; }  // bvh_sphere_test_any with tie = none
@@ -1022,6 +1066,7 @@ IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool activ
     prim_out = closest;
 }
 
+IRIS_RADIOMETRIC_BEGIN
 // ---------------------------------------------------------------- sphere light (shape/sphere.rs:77-162)
 IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &smp, V3 &p_out, float &pdf_out) {
     float u0 = gen_0_1(ring, smp);
@@ -1033,7 +1078,7 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
         V3 light_normal = unit_sphere(u0, u1);
         V3 light_point = position + radius * light_normal;
         float area = 4.0f * PI_F * (radius * radius);
-        float pdf = distance_squared(light_point, point) / (dot(light_normal, normalize(light_point - point)) * area);
+        float pdf = fdiv(distance_squared(light_point, point), dot(light_normal, normalize(light_point - point)) * area);
         p_out = light_point;
         pdf_out = rmax(pdf, 0.001f);
         return;
@@ -1042,7 +1087,7 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
     V3 wc = normalize(position - hit.point);
     V3 wc_x, wc_y;
     coordinate_system_from_unit(wc, wc_x, wc_y);
-    float sin_theta_max = radius / dc;
+    float sin_theta_max = fdiv(radius, dc);
     float sin_theta_max_2 = sin_theta_max * sin_theta_max;
     float cos_theta_max = sqrt_nz(rmax(1.0f - sin_theta_max_2, 0.0f));
     float sin_theta_2, cos_theta_;
@@ -1053,7 +1098,7 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
         cos_theta_ = (cos_theta_max - 1.0f) * u0 + 1.0f;
         sin_theta_2 = 1.0f - cos_theta_ * cos_theta_;
     }
-    float cos_alpha = sin_theta_2 / sin_theta_max + cos_theta_ * sqrt_nz(rmax(1.0f - sin_theta_2 / sin_theta_max_2, 0.0f));
+    float cos_alpha = fdiv(sin_theta_2, sin_theta_max) + cos_theta_ * sqrt_nz(rmax(1.0f - fdiv(sin_theta_2, sin_theta_max_2), 0.0f));
     float sin_alpha = sqrt_nz(rmax(1.0f - cos_alpha * cos_alpha, 0.0f));
     float phi = u1 * 2.0f * PI_F;
     float sphi, cphi;
@@ -1074,14 +1119,14 @@ IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &
         float t = sphere_hit_t(stage_sphere(sp), ray, len_squared(ray.d));
         if (t > 0.0f) {
             V3 lp = ray.o + ray.d * t;
-            V3 ln = (lp - position) / radius;
+            V3 ln = div3(lp - position, radius);
             float area = 4.0f * PI_F * (radius * radius);
-            float pdf = distance_squared(lp, point) / (dot(ln, normalize(lp - point)) * area);
+            float pdf = fdiv(distance_squared(lp, point), dot(ln, normalize(lp - point)) * area);
             return rmax(pdf, 0.001f);
         }
         return 0.0f;
     }
-    float sin_theta_max_2 = radius * radius / distance_squared(position, hit.point);
+    float sin_theta_max_2 = fdiv(radius * radius, distance_squared(position, hit.point));
     float cos_theta_max = sqrt_nz(rmax(1.0f - sin_theta_max_2, 0.0f));
     return pdf_cone(cos_theta_max);
 }
@@ -1090,7 +1135,7 @@ IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &
 IRIS_DEV V3 ggx_sample(V3 wo_in, float ax, float ay, DrawRing ring, Sampler &smp) {  // ggx.rs:7-33
     V3 wo = normalize(v3(ax * wo_in.x, ay * wo_in.y, wo_in.z));
     float len_2 = wo.x * wo.x + wo.y * wo.y;
-    V3 t1_v = len_2 > 0.0f ? v3(-wo.y, wo.x, 0.0f) / rsqrt_exact(len_2) : v3(1.0f, 0.0f, 0.0f);
+    V3 t1_v = len_2 > 0.0f ? div3(v3(-wo.y, wo.x, 0.0f), rsqrt_exact(len_2)) : v3(1.0f, 0.0f, 0.0f);
     V3 t2_v = cross(wo, t1_v);
     float r = sqrt_nz(gen_0_1(ring, smp));  // a draw is 0 or at least 2^-32
     float phi = 2.0f * PI_F * gen_0_1(ring, smp);
@@ -1106,7 +1151,7 @@ IRIS_DEV V3 ggx_sample(V3 wo_in, float ax, float ay, DrawRing ring, Sampler &smp
 IRIS_DEV float ggx_evaluate(V3 wh, float ax, float ay) {  // ggx.rs:35-43
     float tan2 = tan_2_theta(wh);
     if (__builtin_isinf(tan2)) return 0.0f;
-    float e = (cos_2_phi(wh) / (ax * ax) + sin_2_phi(wh) / (ay * ay)) * tan2;
+    float e = (fdiv(cos_2_phi(wh), ax * ax) + fdiv(sin_2_phi(wh), ay * ay)) * tan2;
     float ct = cos_theta(wh);
     float ct2 = ct * ct;
     float ope = 1.0f + e;
@@ -1122,7 +1167,7 @@ IRIS_DEV float ggx_lambda(V3 w, float ax, float ay) {  // ggx.rs:45-55
 IRIS_DEV float ggx_g(V3 wo, V3 wh, float ax, float ay) { return rcp_g(1.0f + ggx_lambda(wh, ax, ay) + ggx_lambda(wo, ax, ay)); }
 IRIS_DEV float ggx_g1(V3 w, float ax, float ay) { return rcp_g(1.0f + ggx_lambda(w, ax, ay)); }
 IRIS_DEV float ggx_pdf(V3 wo, V3 wh, float ax, float ay) {  // ggx.rs:61-64
-    return ggx_evaluate(wh, ax, ay) * ggx_g1(wo, ax, ay) * fabs_(dot(wo, wh)) / fabs_(cos_theta(wo));
+    return fdiv(ggx_evaluate(wh, ax, ay) * ggx_g1(wo, ax, ay) * fabs_(dot(wo, wh)), fabs_(cos_theta(wo)));
 }
 
 // ---------------------------------------------------------------- BSDFs (bsdf/*.rs)
@@ -1158,7 +1203,7 @@ IRIS_DEV F4 bsdf_pdf(const iris_bsdf &b, V3 wi, V3 wo) {
     if (b.kind == IRIS_BSDF_LAMBERTIAN) return splat(div_pi(fabs_(cos_theta(wi))));  // lambertian.rs:33-35, mod.rs:56-59
     if (b.kind == IRIS_BSDF_MICROFACET) {                                            // microfacet.rs:59-63
         V3 wh = normalize(wi + wo);
-        return splat(ggx_pdf(wo, wh, b.p0, b.p1) / (4.0f * dot(wo, wh)));
+        return splat(fdiv(ggx_pdf(wo, wh, b.p0, b.p1), 4.0f * dot(wo, wh)));
     }
     return splat(0.0f);  // specular.rs:35-37, fresnel.rs:46-48
 }
@@ -1178,7 +1223,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         V3 wh = ggx_sample(wo, b.p0, b.p1, ring, smp);
         V3 wi = reflect(wo, wh);
         if (!(cos_theta(wo) == 0.0f || dot(wo, wh) < 0.0f || !same_hemisphere(wo, wi))) {
-            float pdf = ggx_pdf(wo, wh, b.p0, b.p1) / (4.0f * dot(wo, wh));
+            float pdf = fdiv(ggx_pdf(wo, wh, b.p0, b.p1), 4.0f * dot(wo, wh));
             wi_out = wi;
             val_out = microfacet_evaluate(sc, b, wi, wo, wl, mono);
             pdf_out = splat(pdf);
@@ -1205,9 +1250,9 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
             if (cos_theta(wo) > 0.0f) { eta_i = eta_a; eta_t = hero(eta_b); }
             else { eta_i = hero(eta_b); eta_t = eta_a; }
             V3 wi;
-            if (refract(wo, face_forward(v3(0.0f, 0.0f, 1.0f), wo), eta_i / eta_t, wi)) {
+            if (refract(wo, face_forward(v3(0.0f, 0.0f, 1.0f), wo), fdiv(eta_i, eta_t), wi)) {
                 F4 ft = ((spectrum_evaluate(sc.spectra[b.spec_b], wl, mono) * (1.0f - hero(fr))) * (eta_i * eta_i)) / (eta_t * eta_t);
-                float hero_value = hero(ft) / fabs_(cos_theta(wi));
+                float hero_value = fdiv(hero(ft), fabs_(cos_theta(wi)));
                 wi_out = wi;
                 val_out = f4(hero_value, 0.0f, 0.0f, 0.0f);
                 pdf_out = f4(1.0f - hero(fr), 0.0f, 0.0f, 0.0f);
@@ -1246,7 +1291,7 @@ IRIS_DEV void env_eval(const SceneDev &sc, V3 d, F4 wl, F4 &le, float &pdf) {
     float4 t = sc.env_texels[idx];
     iris_spectrum sp = {IRIS_SPEC_UPSAMPLED_HDR, t.x, t.y, t.z, t.w};
     le = spectrum_evaluate(sp, wl, false);
-    pdf = sc.env_integral > 0.0f ? ((sc.env_func[idx] / sc.env_integral) * 0.25f) * jac : 0.0f;
+    pdf = sc.env_integral > 0.0f ? (fdiv(sc.env_func[idx], sc.env_integral) * 0.25f) * jac : 0.0f;
 }
 // Piecewise-constant 1-D distribution: the largest idx with cdf[idx] <= u ("CDF search"), then the continuous
 // position inside that bin, in [0, 1].  docs/SPEC.md states the search as a bisection; on the GPU a bisection is
@@ -1279,9 +1324,9 @@ IRIS_DEV float env_sample_1d(const float *const lvl[3], const uint32_t stride[3]
     float c1 = b + 1u < n ? cdf[b + 1u] : 1.0f;  // cdf[n] = 1 exactly (iris_envmap_tables)
     float den = c1 - c0;
     float du = u - c0;
-    if (den > 0.0f) du = du / den;
+    if (den > 0.0f) du = fdiv(du, den);
     idx = b;
-    return ((float)b + du) / (float)n;
+    return fdiv((float)b + du, (float)n);
 }
 IRIS_DEV V3 env_sample(const SceneDev &sc, float u0, float u1) {
     uint32_t r, c;
@@ -1291,6 +1336,7 @@ IRIS_DEV V3 env_sample(const SceneDev &sc, float u0, float u1) {
     return normalize(oct_point(2.0f * uu - 1.0f, 2.0f * vv - 1.0f));
 }
 
+IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- path state and the two stages' per-lane work
 struct Counters { uint32_t samples, bounces, rays; unsigned long long sphere_tests; };
 
@@ -1336,9 +1382,9 @@ IRIS_DEV CamSample camera_sample(const CamDev &cam, const FrameDev &fr, SobolLds
     float tx = cx + j0, ty = cy + j1, tz = 0.0f + 0.0f;
     const float *m = cam.m;  // matrix.rs:168-196
     float w = m[12] * tx + m[13] * ty + m[14] * tz + m[15];
-    V3 target = div3(v3(m[0] * tx + m[1] * ty + m[2] * tz + m[3], m[4] * tx + m[5] * ty + m[6] * tz + m[7], m[8] * tx + m[9] * ty + m[10] * tz + m[11]), w);
+    V3 target = div3_x(v3(m[0] * tx + m[1] * ty + m[2] * tz + m[3], m[4] * tx + m[5] * ty + m[6] * tz + m[7], m[8] * tx + m[9] * ty + m[10] * tz + m[11]), w);
     V3 origin = v3(cam.px, cam.py, cam.pz);
-    cs.d = ray_new(origin, target - origin).d;
+    cs.d = normalize_x(target - origin);  // ray.rs:14-19
     return cs;
 }
 // Starts the path of a camera sample in `ps`; the unread half of set 0 goes to the lane's ring.
@@ -1359,6 +1405,7 @@ IRIS_DEV void raygen(const CamDev &cam, const FrameDev &fr, SobolLds tab, DrawRi
     path_begin(cam, cs, sample_index, ring, ps);
 }
 
+IRIS_RADIOMETRIC_BEGIN
 // What `radiance` returns for a finished path, as XYZ (tile.rs:159-162)
 template <int INTEG>
 IRIS_DEV V3 path_xyz(const PathState &ps) {
@@ -1517,12 +1564,12 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 df->want1 = true;
                 df->ray1 = shadow1;
                 cnt.rays++;
-                df->limit1 = len(light_pos - shadow1.o) / len(shadow1.d) - IRIS_RAY_EPSILON;
+                df->limit1 = fdiv(len(light_pos - shadow1.o), len(shadow1.d)) - IRIS_RAY_EPSILON;
                 V3 shading_wi = world_to_shading(hit, shadow1.d);
                 F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl, MONO);
                 F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
                 float cos_t = fabs_(cos_theta(shading_wi));
-                float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : light_pdf / (hero(bsdf_pdfs) + light_pdf);
+                float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : fdiv(light_pdf, hero(bsdf_pdfs) + light_pdf);
                 df->c1 = ((((mis_weight * light_emission) * bsdf_values) * cos_t) / light_pdf).v[0];
             }
         } else if (st.bvh) {
@@ -1533,7 +1580,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             // the first occluder, and the limit culls boxes from the start.
             const bool env_lane = ENV && env_pick;
             float limit = __builtin_inff();
-            if (want1 && !env_lane) limit = len(light_pos - shadow1.o) / len(shadow1.d) - IRIS_RAY_EPSILON;
+            if (want1 && !env_lane) limit = fdiv(len(light_pos - shadow1.o), len(shadow1.d)) - IRIS_RAY_EPSILON;
             int occluder = -1;
             float lim = limit;
             if (want1) bvh_closest<true>(sc, st, shadow1, len_squared(shadow1.d), lim, occluder, cnt.sphere_tests);
@@ -1549,7 +1596,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             } else if (ENV && env_pick) {
                 visible = sp1 < 0;
             } else {
-                float target_t = len(light_pos - shadow1.o) / len(shadow1.d);
+                float target_t = fdiv(len(light_pos - shadow1.o), len(shadow1.d));
                 visible = st1 > target_t - IRIS_RAY_EPSILON;
             }
             if (visible) {
@@ -1557,7 +1604,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 F4 bsdf_values = bsdf_evaluate(sc, bsdf, shading_wi, shading_wo, wl, MONO);
                 F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
                 float cos_t = fabs_(cos_theta(shading_wi));
-                float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : light_pdf / (hero(bsdf_pdfs) + light_pdf);
+                float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : fdiv(light_pdf, hero(bsdf_pdfs) + light_pdf);
                 direct = direct + (((mis_weight * light_emission) * bsdf_values) * cos_t) / light_pdf;
             }
         }
@@ -1603,7 +1650,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 float lpdf;
                 if (ENV && env_pick) env_eval(sc, shadow2.d, wl, light_emission, lpdf);
                 else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
-                float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : hero(bs_pdfs) / (hero(bs_pdfs) + lpdf);
+                float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : fdiv(hero(bs_pdfs), hero(bs_pdfs) + lpdf);
                 const F4 c2 = (((mis_weight * light_emission) * bs_values) * bs_cos) / hero(bs_pdfs);
                 if (DEFER) { df->has2 = true; df->c2 = c2.v[0]; }
                 else direct = direct + c2;
@@ -1643,5 +1690,6 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
     }
     return alive;
 }
+IRIS_RADIOMETRIC_END
 
 }  // namespace iris

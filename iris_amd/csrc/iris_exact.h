@@ -74,7 +74,7 @@ IRIS_EX float rcp_refined(float d) {
 }
 IRIS_EX Recip recip_for(float d) { Recip r = {rcp_refined(d)}; return r; }
 #ifndef IRIS_EXACT_DIV_STEPS
-#define IRIS_EXACT_DIV_STEPS 2
+#define IRIS_EXACT_DIV_STEPS 1
 #endif
 IRIS_EX float div_by(float n, float d, Recip r) {
     float q = n * r.y;

@@ -10,6 +10,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # IRIS_HIP_LIB: alternative build of the same library (tuning experiments)
 LIB_PATH = os.environ.get("IRIS_HIP_LIB") or os.path.join(HERE, "lib", "libiris_hip.so")
+# The opt-in relaxed-arithmetic build of the same sources (iris_device.h, IRIS_RELAXED): never loaded unless asked for.
+LIB_RELAXED_PATH = os.path.join(HERE, "lib", "libiris_hip_relaxed.so")
 
 IRIS_OK = 0
 TRACE_MAX_DEPTH = 64
@@ -81,18 +83,19 @@ class Trace(C.Structure):
                 ("draws", C.c_uint32)]
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libiris_hip.so; raises IrisError if it has not been built (python -m iris_amd.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise IrisError("libiris_hip.so is missing at %s: build it with `python -m iris_amd.build`; "
-                        "there is no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+def load(relaxed=False):
+    """Load libiris_hip.so (relaxed: libiris_hip_relaxed.so, the opt-in build whose film is not the reference's bit for bit);
+    raises IrisError if it has not been built (python -m iris_amd.build)."""
+    path = LIB_RELAXED_PATH if relaxed else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise IrisError("%s is missing at %s: build it with `python -m iris_amd.build`; "
+                        "there is no CPU fallback" % (os.path.basename(path), path))
+    L = C.CDLL(path)
     vp, fp, u32 = C.c_void_p, C.POINTER(C.c_float), C.c_uint32
     u32p, i32p = C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
     sig = {
@@ -134,5 +137,5 @@ def load():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = L
+    _libs[path] = L
     return L

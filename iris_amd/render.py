@@ -64,8 +64,10 @@ class Render:
 class HipWavefront:
     """One GPU's wavefront path tracer (an iris_ctx)."""
 
-    def __init__(self, device=0, **options):
-        self.L = ffi.load()
+    def __init__(self, device=0, relaxed=False, **options):
+        """relaxed: the opt-in build whose radiometric arithmetic uses 1-ulp reciprocals/roots and contraction (faster; the film
+        then meets the statistical image gate, not the reference's bits).  Default: the exact build."""
+        self.L = ffi.load(relaxed=relaxed)
         self.ctx = C.c_void_p()
         rc = self.L.iris_ctx_create(int(device), C.byref(self.ctx))
         if rc != ffi.IRIS_OK:
