@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--env-size", type=int, default=1024, help="environment map is env_size x env_size texels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-c", action="store_true", help="skip the extra strong-scaling leg (BASELINE config C: 3840x2160 at 4096 spp in all)")
+    ap.add_argument("--no-relaxed", action="store_true", help="skip the extra leg on the opt-in relaxed-arithmetic build (reported beside `value`, never as it)")
     ap.add_argument("--multi-kernel", action="store_true", help="launch the two stages as separate kernels")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="iris_ctx_set_option tuning knob (repeatable)")
     args = ap.parse_args()
@@ -214,6 +215,34 @@ def main():
                     "ranks": dist.get_world_size() if world > 1 else 1}
         del cfilm
 
+    # ---- third leg, one GPU only: the same workload on the opt-in relaxed-arithmetic build (libiris_hip_relaxed.so: 1-ulp
+    # reciprocals/roots and contraction in the radiometric code; camera samples and sphere tests exact).  Its film meets the
+    # statistical image gate (tests/test_gpu_relaxed.py), not the reference's bits, so it is reported BESIDE the headline value.
+    relaxed = None
+    if world == 1 and not args.no_relaxed and os.path.exists(iris_amd.ffi.LIB_RELAXED_PATH):
+        rgpu = iris_amd.HipWavefront(device=local_rank, relaxed=True, **opts)
+        rgpu.upload(scene)
+        rsteps = max(1, min(args.steps, 2))
+        if args.warmup:
+            rgpu.render_film_device(render, film.data_ptr(), spp_begin=begin, spp_count=count)
+        fence()
+        r0 = time.perf_counter()
+        r_kernel_ms, r_flops, rst = 0.0, 0.0, None
+        for _ in range(rsteps):
+            rgpu.render_film_device(render, film.data_ptr(), spp_begin=begin, spp_count=count)
+            rst = rgpu.stats()
+            r_kernel_ms += rst.kernel_ms
+            r_flops += algorithmic_flops(rst) - (F_CAM + F_ISECT * len(scene.primitives)) * rst.sky_samples
+        fence()
+        relapsed = time.perf_counter() - r0
+        r_tflops = r_flops / (r_kernel_ms * 1e-3) / 1e12 if r_kernel_ms > 0 else 0.0
+        relaxed = {"value": round(args.width * args.height * spp_total * rsteps / 1e6 / relapsed, 2), "unit": "Msamples/s", "steps": rsteps,
+                   "ms_per_step": round(relapsed * 1e3 / rsteps, 3), "kernel_ms_per_launch": round(r_kernel_ms / (rsteps * max(1, rst.chunks)), 3),
+                   "roofline_achieved": round(r_tflops, 3), "roofline_frac": round(r_tflops / PEAK_FP32_VALU_TFLOPS, 4),
+                   "parity": "statistical image gate (relMSE < 1e-3 + z-test), not bit-exact; camera samples, wavelengths and the hit of a given ray are bit-exact",
+                   "build": "libiris_hip_relaxed.so (-DIRIS_RELAXED=1)"}
+        rgpu.close()
+
     workload_key = "%s_%dx%dx%d%s" % (args.scene, args.width, args.height, args.spp, "".join("_%s=%d" % kv for kv in sorted(opts.items())))
     if rank == 0:
         samples_per_step = args.width * args.height * spp_total
@@ -263,6 +292,8 @@ def main():
         }
         if config_c is not None:
             line["config_c_strong"] = config_c
+        if relaxed is not None:
+            line["relaxed_mode"] = relaxed
         if world == 1 and not args.no_cpu_baseline:
             n_threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
             line["cpu_baseline"] = cpu_baseline(n_threads)

@@ -73,6 +73,8 @@ extern "C" {
     pub fn iris_upsample_table_resolution(table: *const iris_upsample_table) -> u32;
     pub fn iris_upsample_get_spectrum(table: *const iris_upsample_table, rgb: *const f32, out: *mut iris_spectrum) -> c_int;
     pub fn iris_upsample_get_spectrum_hdr(table: *const iris_upsample_table, rgb: *const f32, out: *mut iris_spectrum) -> c_int;
+    pub fn iris_upsample_table_upload(ctx: *mut iris_ctx, table: *const iris_upsample_table) -> c_int;
+    pub fn iris_upsample_get_spectrum_hdr_batch(ctx: *mut iris_ctx, rgb: *const f32, n: usize, max_hdr: f32, texels: *mut f32, importance: *mut f32, on_device: c_int, stream: *mut c_void) -> c_int;
     pub fn iris_envmap_tables(map: *const iris_envmap_desc, func: *mut f32, cond_cdf: *mut f32, marg_cdf: *mut f32, integral: *mut f32) -> c_int;
     pub fn iris_oct_to_dir(u: f32, v: f32, dir: *mut f32);
     pub fn iris_dir_to_oct(dir: *const f32, uv: *mut f32);

@@ -244,6 +244,22 @@ int iris_envmap_from_latlong(const float *rgb, uint32_t width, uint32_t height, 
 int iris_envmap_texels_from_rgb(const iris_upsample_table *table, const float *rgb, size_t n_texels, float max_hdr,
                                 float *texels, float *importance);
 
+/* The UpsampleTable resident in HBM and get_spectrum_hdr as a batch on the GPU (north_star: "table resident in HBM/L2").
+ * The reference converts one RGB value at a time on the CPU while it builds a scene (upsample.rs:46-106); an HDR
+ * environment map is a million of them.
+ * iris_upsample_table_upload: copies the table's coefficients (9 * res^3 floats) and scale array to the context's GPU;
+ *   they stay there until the context is destroyed or another table is uploaded.
+ * iris_upsample_get_spectrum_hdr_batch: n RGB triples -> texels[4*n] = (c0, c1, c2, hdr_coefficient) per value, exactly
+ *   the iris_spectrum iris_upsample_get_spectrum_hdr returns for it (bit for bit: same f32 operations in the same order,
+ *   find_interval included), with the clamp of the HDR factor at `max_hdr` as in iris_envmap_texels_from_rgb;
+ *   importance[n] (may be NULL) = Rec.709 luminance.  on_device != 0: rgb, texels (16-byte aligned) and importance are
+ *   DEVICE pointers on the context's GPU, the kernel is enqueued on `stream` and the call returns without waiting;
+ *   on_device == 0: they are HOST pointers, staged through device memory, and the call returns when texels is filled.
+ *   IRIS_E_STATE without an uploaded table. */
+int iris_upsample_table_upload(iris_ctx *ctx, const iris_upsample_table *table);
+int iris_upsample_get_spectrum_hdr_batch(iris_ctx *ctx, const float *rgb, size_t n, float max_hdr, float *texels,
+                                         float *importance, int on_device, void *stream);
+
 /* Radiance RGBE picture (.hdr) -> linear RGB f32, rows top to bottom: the file format of the environment maps the
  * reference's authors keep beside the code (`.hdr` files under data/, .gitignore:7; its own reader is a README.md:36 TODO).
  * Call with rgb == NULL to get the size, then with a buffer of width*height*3 floats (rgb_floats = its length).

@@ -223,6 +223,13 @@ void iris_upsample_table_free(iris_upsample_table *t) { delete t; }
 
 uint32_t iris_upsample_table_resolution(const iris_upsample_table *t) { return t ? (uint32_t)t->resolution : 0u; }
 
+// for iris_upsample_table_upload (iris_kernels.hip): the table's arrays.  Internal: not exported, not in the header.
+__attribute__((visibility("hidden"))) void iris_host_upsample_arrays(const iris_upsample_table *t, const float **coefficients, size_t *n_coefficients, const float **scale) {
+    *coefficients = t->coefficients.data();
+    *n_coefficients = t->coefficients.size();
+    *scale = t->scale.data();
+}
+
 int iris_upsample_get_spectrum(const iris_upsample_table *t, const float rgb[3], iris_spectrum *out) {
     if (!t || !rgb || !out) return IRIS_E_ARG;
     float c[3];

@@ -358,7 +358,10 @@ template <int CLS, bool BVH> struct PqGeom {  // < CAP - 63 queued when a genera
 // leaves its visibility query to the next loop top (shade_bounce<.., DEFER>), where the paths that ended wait for it as LANE_FIN.
 template <int CLS, bool BVH> struct PoolGeom { static constexpr bool ON = BVH && CLS == IRIS_CLS_LAMBERT_CONSTANT; };
 template <int INTEG, int CLS, bool BVH>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_regwave(WfArgs a) {
+#ifndef IRIS_REG_WAVES_GENERAL
+#define IRIS_REG_WAVES_GENERAL 3
+#endif
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLS == IRIS_CLS_LAMBERT_CONSTANT ? 3 : IRIS_REG_WAVES_GENERAL))) k_regwave(WfArgs a) {
     constexpr bool POOLED = PoolGeom<CLS, BVH>::ON;
     constexpr uint32_t PQ_CAP = PqGeom<CLS, BVH>::CAP;
     constexpr uint32_t PQ_LOW = PQ_CAP - 63u;  // generate while fewer records than this are queued
@@ -985,6 +988,8 @@ struct iris_ctx {
     int64_t x_park_max = 24, x_fire = 110;
     void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr;
     void *d_env_texels = nullptr, *d_env_func = nullptr, *d_env_cond = nullptr, *d_env_marg = nullptr;
+    float *d_up_coeff = nullptr, *d_up_scale = nullptr;  // UpsampleTable resident in HBM (iris_upsample_table_upload)
+    uint32_t up_res = 0;
     uint32_t bvh_depth = 0;
     // pools
     uint32_t pool_blocks = 0, pool_slots_per_block = 0;
@@ -1446,6 +1451,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
+    dev_free(c->d_up_coeff); dev_free(c->d_up_scale);
     dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_park); dev_free(c->d_sky); dev_free(c->d_work_cursor);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -1905,6 +1911,107 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)); }
 };
 }  // namespace
+
+// ---- UpsampleTable on the device: the table resident in HBM, get_spectrum_hdr as a batch kernel (one thread per RGB value) ----
+// The arithmetic of upsample.rs:46-106 operation for operation in f32 (no contraction, IEEE division), so a texel computed
+// here equals iris_upsample_get_spectrum_hdr's bit for bit.
+__attribute__((visibility("hidden"))) void iris_host_upsample_arrays(const iris_upsample_table *t, const float **coefficients, size_t *n_coefficients, const float **scale);
+namespace {
+__device__ __forceinline__ float up_rust_max(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
+__device__ __forceinline__ float up_rust_min(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
+// min(x as usize, res - 2): Rust's float-to-integer cast saturates and sends NaN to 0
+__device__ __forceinline__ uint32_t up_cell(float x, uint32_t res) { return !(x > 0.0f) ? 0u : (x >= (float)(res - 1u) ? res - 2u : (uint32_t)x); }
+__global__ void __launch_bounds__(BLOCK) k_upsample_hdr(const float *__restrict__ coeff, const float *__restrict__ scale_tab, uint32_t res, const float *__restrict__ rgb_in,
+                                                         size_t n, float max_hdr, float4 *__restrict__ texels, float *__restrict__ importance) {
+    const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (gid >= n) return;
+    const float p0 = rgb_in[3 * gid], p1 = rgb_in[3 * gid + 1], p2 = rgb_in[3 * gid + 2];
+    // get_spectrum_hdr, upsample.rs:46-56
+    const float mx = up_rust_max(up_rust_max(up_rust_max(p0, p1), p2), 1.0f);
+    const float rgb[3] = {p0 / mx, p1 / mx, p2 / mx};
+    // get_spectrum, upsample.rs:59-106
+    uint32_t i = 0u;
+    if (rgb[1] >= rgb[i]) i = 1u;
+    if (rgb[2] >= (i == 1u ? rgb[1] : rgb[0])) i = 2u;
+    const float z = i == 0u ? rgb[0] : (i == 1u ? rgb[1] : rgb[2]);
+    const float xa = i == 0u ? rgb[1] : (i == 1u ? rgb[2] : rgb[0]);  // rgb[(i + 1) % 3]
+    const float ya = i == 0u ? rgb[2] : (i == 1u ? rgb[0] : rgb[1]);  // rgb[(i + 2) % 3]
+    const float sc = (float)(res - 1u) / z;
+    const float x = xa * sc, y = ya * sc;
+    const uint32_t xi = up_cell(x, res), yi = up_cell(y, res);
+    // find_interval, upsample.rs:147-165
+    uint32_t left = 0u;
+    const uint32_t last_interval = res - 2u;
+    uint32_t size = last_interval;
+    while (size > 0u) {
+        const uint32_t half = size / 2u, middle = left + half + 1u;
+        if (scale_tab[middle] < z) { left = middle; size -= half + 1u; }
+        else size = half;
+    }
+    const uint32_t zi = left < last_interval ? left : last_interval;
+    size_t offset = ((((size_t)i * res + zi) * res + yi) * res + xi) * 3u;
+    const size_t dx = 3u, dy = 3u * (size_t)res, dz = 3u * (size_t)res * res;
+    const float x1 = x - (float)xi, x0 = 1.0f - x1, y1 = y - (float)yi, y0 = 1.0f - y1;
+    const float z1 = (z - scale_tab[zi]) / (scale_tab[zi + 1u] - scale_tab[zi]), z0 = 1.0f - z1;
+    float out[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        out[k] = ((coeff[offset] * x0 + coeff[offset + dx] * x1) * y0 + (coeff[offset + dy] * x0 + coeff[offset + dy + dx] * x1) * y1) * z0 +
+                 ((coeff[offset + dz] * x0 + coeff[offset + dz + dx] * x1) * y0 + (coeff[offset + dz + dy] * x0 + coeff[offset + dz + dy + dx] * x1) * y1) * z1;
+        offset += 1u;
+    }
+    texels[gid] = make_float4(out[0], out[1], out[2], up_rust_min(mx, max_hdr));
+    if (importance) importance[gid] = 0.2126f * p0 + 0.7152f * p1 + 0.0722f * p2;
+}
+}  // namespace
+
+int iris_upsample_table_upload(iris_ctx *c, const iris_upsample_table *table) {
+    if (!c) return IRIS_E_ARG;
+    if (!table) return fail(c, IRIS_E_ARG, "no table");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float *coeff, *scale;
+    size_t n_coeff;
+    iris_host_upsample_arrays(table, &coeff, &n_coeff, &scale);
+    const uint32_t res = iris_upsample_table_resolution(table);
+    dev_free(c->d_up_coeff); dev_free(c->d_up_scale);
+    c->d_up_coeff = c->d_up_scale = nullptr;
+    c->up_res = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_up_coeff, n_coeff * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_up_scale, res * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->d_up_coeff, coeff, n_coeff * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_up_scale, scale, res * sizeof(float), hipMemcpyHostToDevice));
+    c->up_res = res;
+    return IRIS_OK;
+}
+
+int iris_upsample_get_spectrum_hdr_batch(iris_ctx *c, const float *rgb, size_t n, float max_hdr, float *texels, float *importance, int on_device, void *stream_) {
+    if (!c) return IRIS_E_ARG;
+    if (c->up_res == 0) return fail(c, IRIS_E_STATE, "no table on the device: call iris_upsample_table_upload first");
+    if (!rgb || !texels) return fail(c, IRIS_E_ARG, "bad arguments");
+    if (n == 0) return IRIS_OK;
+    if (n > ((size_t)1 << 31) * BLOCK) return fail(c, IRIS_E_LIMIT, "more than 2^39 values in one batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
+    if (on_device) {
+        if ((uintptr_t)texels % 16 != 0) return fail(c, IRIS_E_ARG, "texels must be 16-byte aligned");
+        hipLaunchKernelGGL(k_upsample_hdr, grid, dim3(BLOCK), 0, stream, (const float *)c->d_up_coeff, (const float *)c->d_up_scale, c->up_res, rgb, n, max_hdr, (float4 *)texels, importance);
+        HIP_TRY(c, hipGetLastError());
+        return IRIS_OK;
+    }
+    DevBuf d_rgb, d_tex, d_imp;
+    HIP_TRY(c, d_rgb.alloc(n * 3 * sizeof(float)));
+    HIP_TRY(c, d_tex.alloc(n * 4 * sizeof(float)));
+    if (importance) HIP_TRY(c, d_imp.alloc(n * sizeof(float)));
+    HIP_TRY(c, hipMemcpyAsync(d_rgb.p, rgb, n * 3 * sizeof(float), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_upsample_hdr, grid, dim3(BLOCK), 0, stream, (const float *)c->d_up_coeff, (const float *)c->d_up_scale, c->up_res, (const float *)d_rgb.p, n, max_hdr, (float4 *)d_tex.p,
+                       importance ? (float *)d_imp.p : nullptr);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(texels, d_tex.p, n * 4 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (importance) HIP_TRY(c, hipMemcpyAsync(importance, d_imp.p, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    return IRIS_OK;
+}
 
 int iris_dbg_sampler(iris_ctx *c, uint32_t n, const uint32_t *xys, uint32_t seed, uint32_t ndraws, float *out) {
     if (!c) return IRIS_E_ARG;

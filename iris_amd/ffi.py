@@ -22,7 +22,7 @@ EXPORTS = (
     "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_render_device_noalloc",
     "iris_noalloc_workspace_bytes", "iris_film_to_rgb",
     "iris_get_stats", "iris_allreduce_films", "iris_allreduce_shutdown", "iris_render_multi", "iris_sample_range", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
-    "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_envmap_tables", "iris_oct_to_dir", "iris_dir_to_oct",
+    "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_upsample_table_upload", "iris_upsample_get_spectrum_hdr_batch", "iris_envmap_tables", "iris_oct_to_dir", "iris_dir_to_oct",
     "iris_envmap_from_latlong", "iris_envmap_texels_from_rgb", "iris_hdr_read", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
 )
 
@@ -121,6 +121,8 @@ def load(relaxed=False):
         "iris_upsample_table_resolution": (C.c_uint32, [vp]),
         "iris_upsample_get_spectrum": (C.c_int, [vp, fp, C.POINTER(Spectrum)]),
         "iris_upsample_get_spectrum_hdr": (C.c_int, [vp, fp, C.POINTER(Spectrum)]),
+        "iris_upsample_table_upload": (C.c_int, [vp, vp]),
+        "iris_upsample_get_spectrum_hdr_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_float, vp, vp, C.c_int, vp]),
         "iris_envmap_tables": (C.c_int, [C.POINTER(EnvmapDesc), fp, fp, fp, fp]),
         "iris_oct_to_dir": (None, [C.c_float, C.c_float, fp]),
         "iris_dir_to_oct": (None, [fp, fp]),

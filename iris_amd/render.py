@@ -125,6 +125,26 @@ class HipWavefront:
                                                C.c_void_p(stream or 0))
         _check(self.L, self.ctx, rc, "iris_render_device_noalloc")
 
+    # -- UpsampleTable on the device --------------------------------------
+    def upload_upsample_table(self, table):
+        """The RGB -> spectrum table (spectrum/upsample.rs:5-9) resident in this GPU's HBM, for get_spectrum_hdr_batch."""
+        _check(self.L, self.ctx, self.L.iris_upsample_table_upload(self.ctx, table.handle), "iris_upsample_table_upload")
+
+    def get_spectrum_hdr_batch(self, rgb, max_hdr=50.0):
+        """UpsampleTable::get_spectrum_hdr (upsample.rs:46-56) for an (n, 3) array of RGB values on the GPU: returns
+        ((n, 4) texels (c0, c1, c2, hdr_coefficient), (n,) luminance).  Host arrays in and out."""
+        a = np.ascontiguousarray(np.asarray(rgb, np.float32).reshape(-1, 3))
+        n = len(a)
+        texels, imp = np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+        rc = self.L.iris_upsample_get_spectrum_hdr_batch(self.ctx, a.ctypes.data, n, C.c_float(max_hdr), texels.ctypes.data, imp.ctypes.data, 0, None)
+        _check(self.L, self.ctx, rc, "iris_upsample_get_spectrum_hdr_batch")
+        return texels, imp
+
+    def get_spectrum_hdr_batch_device(self, d_rgb_ptr, n, d_texels_ptr, d_importance_ptr=None, max_hdr=50.0, stream=None):
+        """The same on DEVICE buffers of this GPU (raw pointers); enqueued on `stream`, returns without waiting."""
+        rc = self.L.iris_upsample_get_spectrum_hdr_batch(self.ctx, d_rgb_ptr, n, C.c_float(max_hdr), d_texels_ptr, d_importance_ptr, 1, stream)
+        _check(self.L, self.ctx, rc, "iris_upsample_get_spectrum_hdr_batch")
+
     def stats(self):
         st = ffi.Stats()
         _check(self.L, self.ctx, self.L.iris_get_stats(self.ctx, C.byref(st)), "iris_get_stats")

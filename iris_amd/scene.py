@@ -118,12 +118,18 @@ class EnvMap:
         return cls(t)
 
     @classmethod
-    def from_rgb(cls, rgb_oct, table, max_hdr=float("inf")):
+    def from_rgb(cls, rgb_oct, table, max_hdr=float("inf"), gpu=None):
         """Octahedral (H, W, 3) linear-sRGB image -> texels through UpsampleTable::get_spectrum_hdr
         (upsample.rs:46-56; its clamp at 50 is the reference's stop-gap for maps that are NOT importance
-        sampled, so the default here is no clamp); importance = luminance."""
+        sampled, so the default here is no clamp); importance = luminance.
+        gpu: a HipWavefront -- the conversion then runs as one batch on that GPU from the table in its HBM
+        (iris_upsample_get_spectrum_hdr_batch; the same texels bit for bit)."""
         rgb = np.ascontiguousarray(rgb_oct, np.float32)
         h, w = rgb.shape[:2]
+        if gpu is not None:
+            gpu.upload_upsample_table(table)
+            texels, imp = gpu.get_spectrum_hdr_batch(rgb.reshape(-1, 3), max_hdr=max_hdr)
+            return cls(texels.reshape(h, w, 4), imp.reshape(h, w))
         texels = np.zeros((h, w, 4), np.float32)
         imp = np.zeros((h, w), np.float32)
         fp = C.POINTER(C.c_float)

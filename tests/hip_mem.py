@@ -52,3 +52,30 @@ class DeviceFilm:
             self.ptr = C.c_void_p()
 
     __del__ = free
+
+
+# ---- plain buffers ----
+def alloc(nbytes):
+    p = C.c_void_p()
+    assert hip().hipMalloc(C.byref(p), max(int(nbytes), 16)) == 0
+    return p.value
+
+
+def free(ptr):
+    if ptr:
+        hip().hipFree(C.c_void_p(ptr))
+
+
+def to_device(ptr, array):
+    a = np.ascontiguousarray(array)
+    assert hip().hipMemcpy(C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0  # hipMemcpyHostToDevice
+
+
+def to_host(ptr, shape, dtype):
+    out = np.empty(shape, dtype)
+    assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    return out
+
+
+def synchronize():
+    assert hip().hipDeviceSynchronize() == 0
