@@ -64,11 +64,24 @@ IRIS_DEV float fabs_(float x) { return __builtin_fabsf(x); }
 #define IRIS_ALL_LANES(cond) (__ballot(!(cond)) == 0ull)
 // lo <= x <= hi for POSITIVE finite bounds given as bit patterns; false for negative x, NaN and anything outside
 IRIS_DEV bool in_range_bits(float x, uint32_t lo_bits, uint32_t hi_bits) { return (__float_as_uint(x) - lo_bits) <= (hi_bits - lo_bits); }
-// every component is +-0 or at least 2^-100 in magnitude (the residual of the quotient stays exact)
+// every component is +-0 or at least 2^-100 in magnitude (the residual of the quotient stays exact).  Says nothing about large
+// components: for callers whose numerators are bounded by the denominator (normalize: |a.x| <= |a|).
 IRIS_DEV bool numerators_ok(float x, float y, float z) {
     const uint32_t kx = exact::mag_key(x), ky = exact::mag_key(y), kz = exact::mag_key(z);
     const uint32_t k = kx < ky ? (kx < kz ? kx : kz) : (ky < kz ? ky : kz);  // v_min3_u32
     return k >= IRIS_EX_KEY(IRIS_EX_BITS_2M100);
+}
+// every component is +-0 or between 2^-60 and 2^60 in magnitude: with a denominator in [2^-60, 2^60] the quotient is
+// 0 or in [2^-120, 2^120] -- it neither overflows (an infinite or huge numerator would turn the residual
+// into inf - inf) nor leaves the normal range
+IRIS_DEV bool numerators_moderate(float x, float y, float z) {
+    // integer tests on the magnitude bits, so that a signalling NaN beside an infinity cannot hide it (a float max would return
+    // the quieted NaN, which compares false with everything): any NaN or infinity fails, and the compiler's expansion runs
+    const uint32_t mx = __float_as_uint(x) << 1, my = __float_as_uint(y) << 1, mz = __float_as_uint(z) << 1;
+    const uint32_t kx = mx - 2u, ky = my - 2u, kz = mz - 2u;  // exact::mag_key
+    const uint32_t lo = kx < ky ? (kx < kz ? kx : kz) : (ky < kz ? ky : kz);  // v_min3_u32; +-0 is at the top
+    const uint32_t hi = mx > my ? (mx > mz ? mx : mz) : (my > mz ? my : mz);  // v_max3_u32; +-0 is at the bottom
+    return lo >= IRIS_EX_KEY(IRIS_EX_BITS_2M60) && hi <= (IRIS_EX_BITS_2P60 << 1);
 }
 // Opt-in relaxed arithmetic (a separate build of the library, libiris_hip_relaxed.so: python -m iris_amd.build): the RADIOMETRIC
 // code -- light sampling, BSDFs, MIS weights, spectra, the environment map, i.e. everything between a hit and the next ray --
@@ -203,7 +216,7 @@ IRIS_DEV float len(V3 a) { return sqrt_g(len_squared(a)); }
 // a / d with one reciprocal for the three quotients; any d, any numerators (outside the proven domain: three divisions)
 IRIS_DEV V3 div3_x(V3 a, float d) {
 #if IRIS_EXACT_FAST
-    if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(d, IRIS_EX_BITS_2M60, IRIS_EX_BITS_2P60) && numerators_ok(a.x, a.y, a.z)), 1)) {
+    if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(d, IRIS_EX_BITS_2M60, IRIS_EX_BITS_2P60) && numerators_moderate(a.x, a.y, a.z)), 1)) {
         const exact::Recip y = exact::recip_for(d);
         return v3(exact::div_by(a.x, d, y), exact::div_by(a.y, d, y), exact::div_by(a.z, d, y));
     }
