@@ -283,6 +283,29 @@ IRIS_DEV F4 operator/(F4 a, float s) { return a / splat(s); }
 IRIS_DEV F4 operator/(float s, F4 a) { return splat(s) / a; }
 IRIS_DEV F4 operator+(float s, F4 a) { return splat(s) + a; }
 IRIS_DEV float hero(F4 a) { return a.v[0]; }
+// a / d for the four wavelengths with ONE reciprocal (hwss_naive.rs divides a SpectralSample by a scalar pdf in several places):
+// 3 + 4 x 3 instructions instead of 4 x 11, when every lane's denominator is in [2^-60, 2^60] and its numerators are zero or
+// in [2^-60, 2^60] (wave-uniform test, as in div3); otherwise four IEEE divisions.  mono (a compile-time constant at every call
+// site): the four components are one value by construction, and one plain division is cheaper than the test.
+IRIS_DEV F4 div4(F4 a, float d, bool mono) {
+    if (mono) return splat(fdiv(a.v[0], d));
+#if IRIS_RELAXED
+    const float y = __builtin_amdgcn_rcpf(d);
+    return f4(a.v[0] * y, a.v[1] * y, a.v[2] * y, a.v[3] * y);
+#else
+#if IRIS_EXACT_FAST
+    const uint32_t m0 = __float_as_uint(a.v[0]) << 1, m1 = __float_as_uint(a.v[1]) << 1, m2 = __float_as_uint(a.v[2]) << 1, m3 = __float_as_uint(a.v[3]) << 1;
+    const uint32_t k0 = m0 - 2u, k1 = m1 - 2u, k2 = m2 - 2u, k3 = m3 - 2u;  // exact::mag_key: +-0 at the top
+    const uint32_t k01 = k0 < k1 ? k0 : k1, lo = k01 < k2 ? (k01 < k3 ? k01 : k3) : (k2 < k3 ? k2 : k3);
+    const uint32_t m01 = m0 > m1 ? m0 : m1, hi = m01 > m2 ? (m01 > m3 ? m01 : m3) : (m2 > m3 ? m2 : m3);
+    if (__builtin_expect(IRIS_ALL_LANES(in_range_bits(d, IRIS_EX_BITS_2M60, IRIS_EX_BITS_2P60) && lo >= IRIS_EX_KEY(IRIS_EX_BITS_2M60) && hi <= (IRIS_EX_BITS_2P60 << 1)), 1)) {
+        const exact::Recip y = exact::recip_for(d);
+        return f4(exact::div_by(a.v[0], d, y), exact::div_by(a.v[1], d, y), exact::div_by(a.v[2], d, y), exact::div_by(a.v[3], d, y));
+    }
+#endif
+    return f4(a.v[0] / d, a.v[1] / d, a.v[2] / d, a.v[3] / d);
+#endif
+}
 // vec4.rs:55-57: f32x4::reduce_sum is the ordered reduction starting from -0.0
 IRIS_DEV float sum(F4 a) { return ((((-0.0f) + a.v[0]) + a.v[1]) + a.v[2]) + a.v[3]; }
 
@@ -1205,7 +1228,7 @@ IRIS_DEV F4 microfacet_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V
     float d = ggx_evaluate(wh, b.p0, b.p1);
     float f = fresnel_dielectric(dot(wi, wh_facing), 1.5f, 1.0f);
     float g = ggx_g(wo, wh, b.p0, b.p1);
-    return (((spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) * d) * g) * f) / (4.0f * cos_theta_o * cos_theta_i);
+    return div4(((spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) * d) * g) * f, 4.0f * cos_theta_o * cos_theta_i, mono);
 }
 IRIS_DEV F4 bsdf_evaluate(const SceneDev &sc, const iris_bsdf &b, V3 wi, V3 wo, F4 wl, bool mono) {
     if (b.kind == IRIS_BSDF_LAMBERTIAN) return lambertian_value(sc, b, wl, mono);  // lambertian.rs:24-31
@@ -1244,7 +1267,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
     } else if (b.kind == IRIS_BSDF_SPECULAR) {  // specular.rs:39-49
         V3 wi = v3(-wo.x, -wo.y, wo.z);
         wi_out = wi;
-        val_out = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / fabs_(cos_theta(wi));
+        val_out = div4(spectrum_evaluate(sc.spectra[b.spec_a], wl, mono), fabs_(cos_theta(wi)), mono);
         pdf_out = splat(1.0f);
     } else if (b.kind == IRIS_BSDF_FRESNEL) {  // fresnel.rs:30-34, 50-102
         const float eta_a = 1.0f;
@@ -1254,7 +1277,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
         for (int k = 0; k < 4; k++) fr.v[k] = fresnel_dielectric(cos_theta(wo), eta_a, eta_b.v[k]);
         if (gen_0_1(ring, smp) < hero(fr)) {
             V3 wi = v3(-wo.x, -wo.y, wo.z);
-            F4 bs = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono) / fabs_(cos_theta(wi));
+            F4 bs = div4(spectrum_evaluate(sc.spectra[b.spec_a], wl, mono), fabs_(cos_theta(wi)), mono);
             wi_out = wi;
             val_out = bs * fr;
             pdf_out = fr;
@@ -1264,7 +1287,7 @@ IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, 
             else { eta_i = hero(eta_b); eta_t = eta_a; }
             V3 wi;
             if (refract(wo, face_forward(v3(0.0f, 0.0f, 1.0f), wo), fdiv(eta_i, eta_t), wi)) {
-                F4 ft = ((spectrum_evaluate(sc.spectra[b.spec_b], wl, mono) * (1.0f - hero(fr))) * (eta_i * eta_i)) / (eta_t * eta_t);
+                F4 ft = div4((spectrum_evaluate(sc.spectra[b.spec_b], wl, mono) * (1.0f - hero(fr))) * (eta_i * eta_i), eta_t * eta_t, mono);
                 float hero_value = fdiv(hero(ft), fabs_(cos_theta(wi)));
                 wi_out = wi;
                 val_out = f4(hero_value, 0.0f, 0.0f, 0.0f);
@@ -1583,7 +1606,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
                 float cos_t = fabs_(cos_theta(shading_wi));
                 float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : fdiv(light_pdf, hero(bsdf_pdfs) + light_pdf);
-                df->c1 = ((((mis_weight * light_emission) * bsdf_values) * cos_t) / light_pdf).v[0];
+                df->c1 = div4(((mis_weight * light_emission) * bsdf_values) * cos_t, light_pdf, MONO).v[0];
             }
         } else if (st.bvh) {
             // Scene::ray_hits_point and the map's visibility test (scene.rs:134-149) ask only whether the closest hit lies
@@ -1618,7 +1641,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 F4 bsdf_pdfs = bsdf_pdf(bsdf, shading_wi, shading_wo);
                 float cos_t = fabs_(cos_theta(shading_wi));
                 float mis_weight = HWSS ? balance_heuristic_2(splat(light_pdf), bsdf_pdfs) : fdiv(light_pdf, hero(bsdf_pdfs) + light_pdf);
-                direct = direct + (((mis_weight * light_emission) * bsdf_values) * cos_t) / light_pdf;
+                direct = direct + div4(((mis_weight * light_emission) * bsdf_values) * cos_t, light_pdf, MONO);
             }
         }
         // BSDF sampling
@@ -1664,7 +1687,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 if (ENV && env_pick) env_eval(sc, shadow2.d, wl, light_emission, lpdf);
                 else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
                 float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : fdiv(hero(bs_pdfs), hero(bs_pdfs) + lpdf);
-                const F4 c2 = (((mis_weight * light_emission) * bs_values) * bs_cos) / hero(bs_pdfs);
+                const F4 c2 = div4(((mis_weight * light_emission) * bs_values) * bs_cos, hero(bs_pdfs), MONO);
                 if (DEFER) { df->has2 = true; df->c2 = c2.v[0]; }
                 else direct = direct + c2;
             }
@@ -1687,12 +1710,12 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         if (hero(bsdf_pdfs) == 0.0f || cos_t == 0.0f) {
             alive = false;
         } else {
-            ps.thr = ps.thr * ((bsdf_values * cos_t) / hero(bsdf_pdfs));
+            ps.thr = ps.thr * div4(bsdf_values * cos_t, hero(bsdf_pdfs), MONO);
             if (HWSS) ps.ppdf = ps.ppdf * bsdf_pdfs;
             if (ps.bounce >= fr.min_depth) {
                 float p = rmin(sum(ps.thr), 0.95f);
                 if (gen_0_1(ring, ps.smp) > p) alive = false;
-                else ps.thr = ps.thr / splat(p);
+                else ps.thr = div4(ps.thr, p, MONO);
             }
             if (alive) {
                 ps.ray = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);

@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "../../iris_amd/csrc/iris_device.h"  // the guarded wrappers (sqrt_g, normalize, div3, div_pi, rcp_g, first_positive_root); includes iris_exact.h
+#include "../../iris_amd/csrc/iris_device.h"  // the guarded wrappers (sqrt_g, normalize, div3, div4, div_pi, rcp_g, first_positive_root); includes iris_exact.h
 
 #define CHECK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(r_)); std::exit(2); } } while (0)
 
@@ -128,6 +128,12 @@ __global__ void k_wrappers(Report *rep, uint32_t rounds) {
             if (!same(got.x, x / d)) record(rep, x, d, got.x, x / d);
             if (!same(got.y, y / d)) record(rep, y, d, got.y, y / d);
             if (!same(got.z, z / d)) record(rep, z, d, got.z, z / d); }
+        {   const float w = any_float(s, mode, odd);
+            const iris::F4 got = iris::div4(iris::f4(x, y, z, w), d, false);
+            if (!same(got.v[0], x / d)) record(rep, x, d, got.v[0], x / d);
+            if (!same(got.v[1], y / d)) record(rep, y, d, got.v[1], y / d);
+            if (!same(got.v[2], z / d)) record(rep, z, d, got.v[2], z / d);
+            if (!same(got.v[3], w / d)) record(rep, w, d, got.v[3], w / d); }
         {   const iris::V3 got = iris::normalize(v);
             const float l = __builtin_sqrtf((x * x + y * y) + z * z);
             if (!same(got.x, x / l)) record(rep, x, l, got.x, x / l);
@@ -140,7 +146,7 @@ __global__ void k_wrappers(Report *rep, uint32_t rounds) {
             if (!(want > 0.0f)) want = (-half_b + root) / a;
             const bool hit_got = got > 0.0f, hit_want = want > 0.0f;
             if (hit_got != hit_want || (hit_want && !same(got, want))) record(rep, half_b, root, got, want); }
-        tested += 12ull;
+        tested += 16ull;
     }
     atomicAdd(&rep->tested, tested);
 }
