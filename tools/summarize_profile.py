@@ -44,3 +44,23 @@ for k, cs in agg.items():
     for c, v in sorted(cs.items()):
         n = len(ndisp[(k, c)])
         print("   %-28s %18.0f   (%d dispatches, %.4g per dispatch)" % (c, v, n, v / max(1, n)))
+
+# ---- HBM traffic of the dominant kernel per launch, for bench.py's roofline.traffic (profiles/traffic.json) ----
+# MI355X_MICROARCH.md, "HBM": FETCH_SIZE and WRITE_SIZE come from separate --pmc passes (they do not fit one), both in KiB;
+# on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so it is doubled; WRITE_SIZE is taken as it is.  The
+# doubling is calibrated for wide coalesced reads; this kernel's reads are mostly L2 hits (the scene), so the figure is an
+# upper bound for them -- stated in the entry.
+if len(sys.argv) > 3 and sys.argv[2] != "-":
+    import json
+    key, dest = sys.argv[2], sys.argv[3]
+    best = max((k for k in agg if k.startswith("k_") and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]),
+               key=lambda k: agg[k].get("SQ_BUSY_CYCLES", 0.0), default=None)
+    if best:
+        fetch = agg[best]["FETCH_SIZE"] / max(1, len(ndisp[(best, "FETCH_SIZE")])) * 1024.0
+        write = agg[best]["WRITE_SIZE"] / max(1, len(ndisp[(best, "WRITE_SIZE")])) * 1024.0
+        entry = {key: {"bytes_per_launch": round(2.0 * fetch + write), "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write),
+                       "kernel": best, "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `%s`, per dispatch; "
+                                                 "FETCH_SIZE doubled (gfx950 counts 128-byte read requests as 64 bytes)" % " ".join(sys.argv[4:] or ["bench.py"])}}
+        json.dump(entry, open(dest, "w"), indent=1)
+        print("== traffic entry ==")
+        print(json.dumps(entry))
