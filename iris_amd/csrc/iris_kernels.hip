@@ -357,11 +357,10 @@ template <int CLS, bool BVH> struct PqGeom {  // < CAP - 63 queued when a genera
 // queries of a wave are traversed together by bvh_pooled, detached from the lanes that own them (iris_device.h); the shade phase
 // leaves its visibility query to the next loop top (shade_bounce<.., DEFER>), where the paths that ended wait for it as LANE_FIN.
 template <int CLS, bool BVH> struct PoolGeom { static constexpr bool ON = BVH && CLS == IRIS_CLS_LAMBERT_CONSTANT; };
+// Three waves per SIMD (168 VGPR) for every class: the general classes would fit 181-189 VGPR without their 28-44 B of scratch at
+// two waves, and lose more to the missing wave than the spills cost (S3 225 -> 279 ms, config E 320 -> 401 ms).
 template <int INTEG, int CLS, bool BVH>
-#ifndef IRIS_REG_WAVES_GENERAL
-#define IRIS_REG_WAVES_GENERAL 3
-#endif
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CLS == IRIS_CLS_LAMBERT_CONSTANT ? 3 : IRIS_REG_WAVES_GENERAL))) k_regwave(WfArgs a) {
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_regwave(WfArgs a) {
     constexpr bool POOLED = PoolGeom<CLS, BVH>::ON;
     constexpr uint32_t PQ_CAP = PqGeom<CLS, BVH>::CAP;
     constexpr uint32_t PQ_LOW = PQ_CAP - 63u;  // generate while fewer records than this are queued

@@ -52,6 +52,20 @@ def test_batch_equals_the_host_lookup_bit_for_bit(gpu, max_hdr):
             assert np.array_equal(bits(list(s.coefficients) + [s.hdr_coefficient]), bits(tex[k]))
 
 
+def test_batch_on_ldr_values_is_get_spectrum(gpu):
+    """For RGB values in [0, 1] the HDR factor is 1 and the division by it exact, so the batch also serves as the device form of
+    UpsampleTable::get_spectrum (upsample.rs:59-106): same three coefficients bit for bit, factor exactly 1."""
+    from iris_amd import UpsampleTable
+    table = UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff"))
+    gpu.upload_upsample_table(table)
+    rgb = np.random.RandomState(77).uniform(0.0, 1.0, size=(512, 3)).astype(np.float32)
+    rgb[0] = (1.0, 1.0, 1.0)
+    tex, _ = gpu.get_spectrum_hdr_batch(rgb)
+    assert np.all(tex[:, 3] == 1.0)
+    for k in range(0, 512, 7):
+        assert np.array_equal(bits(list(table.get_spectrum(rgb[k]).coefficients)), bits(tex[k, :3]))
+
+
 def test_black_and_nan_values_follow_the_host(gpu):
     """A black texel divides by zero in get_spectrum (upsample.rs:67): NaN coefficients on both sides, same HDR factor."""
     from iris_amd import UpsampleTable
