@@ -189,7 +189,7 @@ const char *iris_last_error(const iris_ctx *ctx);
  *   "bvh_min_prims"   scenes with at least this many spheres get a bounding-volume hierarchy at upload and the
  *                     scans traverse it (default 65; 0 = never: every scan tests every sphere like scene.rs:116-166).
  *                     Closest hit and tie rule are the list scan's; iris_stats.sphere_tests then counts the tests made
- *   "bvh_leaf"        spheres per leaf of the hierarchy, 1..7 (default 4)
+ *   "bvh_leaf"        spheres per leaf of the hierarchy, 1..7 (default 2)
  *   "x_park_max", "x_fire"  register-resident kernel, scenes with non-Lambertian BSDFs and no environment map: hits on
  *                     such surfaces are set aside and shaded together; a mixed iteration runs when this many lanes
  *                     wait with one (1..64, default 24) or this many primary ones are queued (1..129, default 110)

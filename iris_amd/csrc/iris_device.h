@@ -1014,7 +1014,12 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
         const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
         if (2u * n_inner >= n_have) {
             IRIS_POOL_STAT(4, 1ull); IRIS_POOL_STAT(5, (unsigned long long)n_inner);
-            if (at_inner) {
+#ifndef IRIS_POOL_INNER_REPS
+#define IRIS_POOL_INNER_REPS 3
+#endif
+#pragma unroll
+            for (int rep = 0; rep < IRIS_POOL_INNER_REPS; rep++)
+            if (have && (ref >> 29) == 0u) {
                 const uint32_t first = ref & 0x1fffffffu;
                 const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
                 const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];

@@ -967,7 +967,7 @@ struct iris_ctx {
     int64_t reg_blocks_per_cu = 8;   // register-resident kernel: at least as many workgroups as a CU can hold (8 waves per SIMD);
                                      // items are claimed from one global counter, so workgroups beyond the resident ones find nothing left
     int64_t bvh_min_prims = 65;   // build a hierarchy for scenes with at least this many spheres (0: never)
-    int64_t bvh_leaf = 4;         // spheres per leaf of the hierarchy (1..7)
+    int64_t bvh_leaf = 2;         // spheres per leaf of the hierarchy (1..7); config D: 2 -> 142.5 ms, 4 -> 145.1, 7 -> 151.2; the general classes measure alike
     int64_t specialize = 1;       // 1: use the kernel compiled for the scene's class; 0: always the general kernel
     int scene_class = IRIS_CLS_GENERAL;
     // scene
