@@ -159,10 +159,20 @@ IRIS_DEV double trig_reduce(double xd, int &quadrant) {
     quadrant = ((int)kd) & 3;
     return r;
 }
-IRIS_DEV double trig_ksin(double r) {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+// The polynomial coefficients are pinned to scalar registers where they are used: left alone, the compiler hoists all
+// twelve binary64 constants into vector registers at the top of the kernel (24 VGPRs for the whole kernel), and in the
+// 168-register kernels spills them and reloads them from scratch around every evaluation.
+// pin (a compile-time constant at every call): false for the Lambertian list kernel, which has registers to spare (119 of
+// 168 when pinned, no spills either way) and is 1 % faster with the constants left in vector registers; true elsewhere
+// (general classes: 44 / 36 B of scratch per lane -> none; pooled hierarchy kernel: 108 -> 28 B, 142 -> 127 ms).
+IRIS_DEV double trig_const(double c, bool pin) {
+    if (pin) asm("" : "+s"(c));
+    return c;
+}
+IRIS_DEV double trig_ksin(double r, bool pin) {
+    const double S1 = trig_const(-1.66666666666666324348e-01, pin), S2 = trig_const(8.33333333332248946124e-03, pin),
+                 S3 = trig_const(-1.98412698298579493134e-04, pin), S4 = trig_const(2.75573137070700676789e-06, pin),
+                 S5 = trig_const(-2.50507602534068634195e-08, pin), S6 = trig_const(1.58969099521155010221e-10, pin);
     double z = r * r;
     double p = __builtin_fma(z, S6, S5);
     p = __builtin_fma(z, p, S4);
@@ -171,10 +181,10 @@ IRIS_DEV double trig_ksin(double r) {
     p = __builtin_fma(z, p, S1);
     return __builtin_fma(r * z, p, r);
 }
-IRIS_DEV double trig_kcos(double r) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+IRIS_DEV double trig_kcos(double r, bool pin) {
+    const double C1 = trig_const(4.16666666666666019037e-02, pin), C2 = trig_const(-1.38888888888741095749e-03, pin),
+                 C3 = trig_const(2.48015872894767294178e-05, pin), C4 = trig_const(-2.75573143513906633035e-07, pin),
+                 C5 = trig_const(2.08757232129817482790e-09, pin), C6 = trig_const(-1.13596475577881948265e-11, pin);
     double z = r * r;
     double p = __builtin_fma(z, C6, C5);
     p = __builtin_fma(z, p, C4);
@@ -184,12 +194,12 @@ IRIS_DEV double trig_kcos(double r) {
     return __builtin_fma(z * z, p, __builtin_fma(z, -0.5, 1.0));
 }
 // sin and cos of the same argument share the reduction and both kernels.
-IRIS_DEV void iris_sincos(float x, float &s_out, float &c_out) {
+IRIS_DEV void iris_sincos(float x, float &s_out, float &c_out, bool pin = true) {
     double xd = (double)x;
     if (!(__builtin_fabs(xd) < 1.0e5)) { s_out = x - x; c_out = x - x; return; }
     int q;
     double r = trig_reduce(xd, q);
-    double ks = trig_ksin(r), kc = trig_kcos(r);
+    double ks = trig_ksin(r, pin), kc = trig_kcos(r, pin);
     double s = (q & 1) ? kc : ks;
     double c = (q & 1) ? ks : kc;
     s_out = (float)((q & 2) ? -s : s);
@@ -504,15 +514,15 @@ IRIS_DEV float gen_golden_ratio(const Sampler &s) {  // sampler.rs:65-71 (u32::M
 IRIS_RADIOMETRIC_BEGIN
 // ---------------------------------------------------------------- warps (sampling/mod.rs), MIS (mis.rs)
 IRIS_DEV float pdf_cone(float cos_theta_max) { return rcp_g(2.0f * PI_F * (1.0f - cos_theta_max)); }  // mod.rs:22-24
-IRIS_DEV V3 unit_sphere(float r1, float r2) {                                                              // mod.rs:26-31
+IRIS_DEV V3 unit_sphere(float r1, float r2, bool pin = true) {                                                              // mod.rs:26-31
     float z = 1.0f - 2.0f * r1;
     float r = sqrt_nz(rmax(1.0f - z * z, 0.0f));
     float phi = 2.0f * PI_F * r2;
     float s, c;
-    iris_sincos(phi, s, c);
+    iris_sincos(phi, s, c, pin);
     return v3(r * c, r * s, z);
 }
-IRIS_DEV V3 cosine_unit_hemisphere(float r1, float r2) {  // mod.rs:33-54
+IRIS_DEV V3 cosine_unit_hemisphere(float r1, float r2, bool pin = true) {  // mod.rs:33-54
     float x_off = 2.0f * r1 - 1.0f, y_off = 2.0f * r2 - 1.0f;
     float x = 0.0f, y = 0.0f;
     if (!(x_off == 0.0f && y_off == 0.0f)) {
@@ -520,7 +530,7 @@ IRIS_DEV V3 cosine_unit_hemisphere(float r1, float r2) {  // mod.rs:33-54
         if (fabs_(x_off) > fabs_(y_off)) { r = x_off; theta = PI_F / 4.0f * fdiv(y_off, x_off); }
         else { r = y_off; theta = (PI_F / 2.0f) - (PI_F / 4.0f) * fdiv(x_off, y_off); }
         float s, c;
-        iris_sincos(theta, s, c);
+        iris_sincos(theta, s, c, pin);
         x = r * c; y = r * s;
     }
     float z = sqrt_nz(rmax(1.0f - x * x - y * y, 0.0f));  // (1 - x*x) is <= 0 or >= 2^-24; minus y*y: <= 0 or >= 2^-49
@@ -1012,7 +1022,10 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
         // ---- one kind of step per round, the kind more lanes are waiting for: inner nodes or leaves ----
         const bool at_inner = have && (ref >> 29) == 0u;
         const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
-        if (2u * n_inner >= n_have) {
+#ifndef IRIS_POOL_INNER_PCT
+#define IRIS_POOL_INNER_PCT 50u
+#endif
+        if (100u * n_inner >= IRIS_POOL_INNER_PCT * n_have) {
             IRIS_POOL_STAT(4, 1ull); IRIS_POOL_STAT(5, (unsigned long long)n_inner);
 #ifndef IRIS_POOL_INNER_REPS
 #define IRIS_POOL_INNER_REPS 3
@@ -1109,14 +1122,14 @@ IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool activ
 
 IRIS_RADIOMETRIC_BEGIN
 // ---------------------------------------------------------------- sphere light (shape/sphere.rs:77-162)
-IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &smp, V3 &p_out, float &pdf_out) {
+IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &smp, V3 &p_out, float &pdf_out, bool pin = true) {
     float u0 = gen_0_1(ring, smp);
     float u1 = gen_0_1(ring, smp);
     V3 position = v3(sp.x, sp.y, sp.z);
     float radius = sp.w;
     V3 point = offset_origin_signed(hit.point, hit.normal, hit.back_face);
     if (distance_squared(position, point) <= radius * radius) {
-        V3 light_normal = unit_sphere(u0, u1);
+        V3 light_normal = unit_sphere(u0, u1, pin);
         V3 light_point = position + radius * light_normal;
         float area = 4.0f * PI_F * (radius * radius);
         float pdf = fdiv(distance_squared(light_point, point), dot(light_normal, normalize(light_point - point)) * area);
@@ -1143,7 +1156,7 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
     float sin_alpha = sqrt_nz(rmax(1.0f - cos_alpha * cos_alpha, 0.0f));
     float phi = u1 * 2.0f * PI_F;
     float sphi, cphi;
-    iris_sincos(phi, sphi, cphi);
+    iris_sincos(phi, sphi, cphi, pin);
     // vec3.rs:87-96 with (x, y, z) = (-wc_x, -wc_y, -wc)
     V3 normal = ((sin_alpha * cphi) * (-wc_x) + (sin_alpha * sphi) * (-wc_y)) + cos_alpha * (-wc);
     V3 sampled_point_local = radius * normalize(normal);
@@ -1248,14 +1261,14 @@ IRIS_DEV F4 bsdf_pdf(const iris_bsdf &b, V3 wi, V3 wo) {
     }
     return splat(0.0f);  // specular.rs:35-37, fresnel.rs:46-48
 }
-IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, DrawRing ring, Sampler &smp, bool mono, V3 &wi_out, F4 &val_out, F4 &pdf_out) {
+IRIS_DEV void bsdf_sample(const SceneDev &sc, const iris_bsdf &b, V3 wo, F4 wl, DrawRing ring, Sampler &smp, bool mono, V3 &wi_out, F4 &val_out, F4 &pdf_out, bool pin = true) {
     wi_out = v3(0.0f, 0.0f, 0.0f);
     val_out = splat(0.0f);
     pdf_out = splat(0.0f);
     if (b.kind == IRIS_BSDF_LAMBERTIAN) {  // lambertian.rs:37-50
         float r1 = gen_0_1(ring, smp);
         float r2 = gen_0_1(ring, smp);
-        V3 wi = cosine_unit_hemisphere(r1, r2);
+        V3 wi = cosine_unit_hemisphere(r1, r2, pin);
         wi = same_hemisphere(wo, wi) ? wi : -wi;
         wi_out = wi;
         val_out = lambertian_value(sc, b, wl, mono);
@@ -1520,6 +1533,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
     // roulette 1 with next-event estimation, BSDF 2 + roulette 1 without
     ensure_draws(tab, ring, ps.smp, NAIVE ? 8u : 3u, active);
     constexpr bool MONO = CLS == IRIS_CLS_LAMBERT_CONSTANT;
+    constexpr bool TRIG_PIN = !(MONO && !DEFER);  // trig_const: the Lambertian list kernel keeps its sin/cos constants in vector registers
     if (MONO) { ps.thr = splat(ps.thr.v[0]); ps.ppdf = splat(ps.ppdf.v[0]); ps.rad = splat(ps.rad.v[0]); }
     bool alive = active;
     Hit hit = {};
@@ -1590,7 +1604,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 light_prim = (int)l.prim;
                 light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl, MONO);
                 light_sphere = sc.spheres[light_prim];
-                sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf);
+                sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf, TRIG_PIN);
                 shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
                 facing_forward = dot(light_pos - hit.point, hit.normal) > 0.0f;
                 want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
@@ -1656,7 +1670,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         float bs_cos = 0.0f;
         if (alive) {
             V3 wi;
-            bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, MONO, wi, bs_values, bs_pdfs);
+            bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, MONO, wi, bs_values, bs_pdfs, TRIG_PIN);
             bs_cos = fabs_(cos_theta(wi));
             shadow2 = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
             want2 = hero(bs_pdfs) > 0.0f;
@@ -1710,7 +1724,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         // hwss_naive.rs:64-88
         V3 wi;
         F4 bsdf_values, bsdf_pdfs;
-        bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, MONO, wi, bsdf_values, bsdf_pdfs);
+        bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, MONO, wi, bsdf_values, bsdf_pdfs, TRIG_PIN);
         float cos_t = fabs_(cos_theta(wi));
         if (hero(bsdf_pdfs) == 0.0f || cos_t == 0.0f) {
             alive = false;
