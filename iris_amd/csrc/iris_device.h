@@ -399,7 +399,9 @@ IRIS_DEV float unit_float_from_bits(uint32_t v) { return __uint_as_float((v >> 9
 // {d0 | d1 << 16, d2 | d3 << 16}.  The table covers the first IRIS_SOBOL_LUT_SETS sets (128 draws: every path
 // of 15 bounces); later sets read the direction vectors bit by bit from the constant table in global memory.
 // Lanes of a wave are at the same set and differ in v, i.e. they read different banks or the same address.
+#ifndef IRIS_SOBOL_LUT_SETS
 #define IRIS_SOBOL_LUT_SETS 32u
+#endif
 #define IRIS_SOBOL_LUT_ENTRIES (IRIS_SOBOL_LUT_SETS * 4u * 16u)
 typedef const uint2 *SobolLds;
 IRIS_DEV uint2 sobol_packed_vectors(uint32_t set, uint32_t bit) {
