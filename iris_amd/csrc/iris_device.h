@@ -18,7 +18,7 @@
 #include "iris_bvh_build.h"  // IRIS_BVH_STACK
 #include "iris_exact.h"
 
-#define IRIS_TABLE_QUAL __device__ const
+#define IRIS_TABLE_QUAL __device__ __attribute__((aligned(16))) const  // 16 bytes: sobol_sample_4d reads the direction vectors four words at a time
 #include "tables/cie_cmf.inc"
 #include "tables/sobol_rev16.inc"
 #define IRIS_SOBOL_SETS 64u
@@ -434,12 +434,22 @@ IRIS_DEV void sobol_sample_4d(SobolLds lut, uint32_t index, uint32_t set, uint32
             x23 ^= v.y;
         }
     } else {
-#pragma unroll 1
-        for (uint32_t b = 0; b < 16; b++) {
-            if ((shuffled_rev << b) & 0x80000000u) {  // index bit b after the shuffle
-                uint2 v = sobol_packed_vectors(set, b);
-                x01 ^= v.x;
-                x23 ^= v.y;
+        // No table in LDS: the 16 packed vectors of the set (128 contiguous bytes of the constant table) are fetched with eight
+        // independent 16-byte loads, four at a time, and masked by the index bits -- one memory round trip per half instead of
+        // one per set bit (the loop this replaces read a vector, waited, and went on to the next bit: up to sixteen dependent
+        // L1/L2 round trips per set, three sets per bounce, in the kernel that is latency-bound to begin with).
+        const uint4 *row = (const uint4 *)&IRIS_SOBOL_REV16[set][0][0];
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            uint4 q[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) q[k] = row[4u * h + k];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t b = 8u * h + 2u * k;  // index bit b after the shuffle = bit 31 - b of shuffled_rev
+                const uint32_t m0 = (uint32_t)((int32_t)(shuffled_rev << b) >> 31), m1 = (uint32_t)((int32_t)(shuffled_rev << (b + 1u)) >> 31);
+                x01 ^= (q[k].x & m0) ^ (q[k].z & m1);
+                x23 ^= (q[k].y & m0) ^ (q[k].w & m1);
             }
         }
     }
