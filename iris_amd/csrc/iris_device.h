@@ -600,12 +600,15 @@ IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- scene on the device
 struct SceneDev {
     const float4 *spheres;      // (cx, cy, cz, r), primitive order
-    const int2 *prim_info;      // (material_index, light_index), -1 = None
+    const int4 *prim_info;      // (material_index, light_index, bits of albedo / PI when the material is Lambertian over a constant spectrum, 0); -1 = None
     const unsigned char *prim_kind;  // 0: Lambertian material or none; 1: any other BSDF (the register kernel sets those hits aside)
     const iris_bsdf *bsdfs;
     const iris_spectrum *spectra;
     const float *spec_over_pi;  // per spectrum: c0 / PI for a constant spectrum (the IEEE quotient, formed once on the host)
     const iris_light *lights;
+    // per light, three float4 read side by side instead of the chain lights -> (spectra, spheres): the light's sphere; (prim,
+    // spectrum kind, c0, c1); (c2, hdr, 0, 0)
+    const float4 *light_rec;
     uint32_t n_prims, n_lights;
     // Bounding-volume hierarchy over the spheres (long lists only; n_bvh_nodes == 0: none).  Node k is two
     // float4: (lo.xyz, first) and (hi.xyz, count); count > 0: leaf holding leaf-ordered spheres
@@ -629,6 +632,13 @@ struct SceneDev {
     float env_integral;
 };
 
+// the emission spectrum and the primitive of light i from its flattened record
+IRIS_DEV iris_spectrum light_spectrum(const SceneDev &sc, uint32_t i, int &prim_out) {
+    const float4 r1 = sc.light_rec[3u * i + 1u], r2 = sc.light_rec[3u * i + 2u];
+    prim_out = __float_as_int(r1.x);
+    iris_spectrum sp = {__float_as_uint(r1.y), r1.z, r1.w, r2.x, r2.y};
+    return sp;
+}
 // shape/mod.rs:14-38
 struct Hit { V3 point, normal, tangeant, bitangeant; bool back_face; };
 IRIS_DEV V3 world_to_shading(const Hit &h, V3 w) { return v3(dot(h.bitangeant, w), dot(h.tangeant, w), dot(h.normal, w)); }
@@ -1243,7 +1253,8 @@ IRIS_DEV V3 reflect(V3 wo, V3 n) { return (-wo) + (2.0f * dot(wo, n)) * n; }  //
 // value that does not depend on the path: iris_scene_upload forms it once (the same correctly rounded f32
 // division), so the three evaluations of a bounce cost a load instead of IEEE divisions.
 IRIS_DEV F4 lambertian_value(const SceneDev &sc, const iris_bsdf &b, F4 wl, bool mono) {
-    if (mono || sc.spectra[b.spec_a].kind == IRIS_SPEC_CONSTANT) return splat(sc.spec_over_pi[b.spec_a]);
+    if (mono) return splat(b.p0);  // the Lambertian/constant class: shade_bounce has put albedo / PI there (from prim_info: no dependent loads)
+    if (sc.spectra[b.spec_a].kind == IRIS_SPEC_CONSTANT) return splat(sc.spec_over_pi[b.spec_a]);
     const F4 v = spectrum_evaluate(sc.spectra[b.spec_a], wl, mono);
     return f4(div_pi(v.v[0]), div_pi(v.v[1]), div_pi(v.v[2]), div_pi(v.v[3]));
 }
@@ -1555,17 +1566,20 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
     if (alive) {
         hit = sphere_frame(sc.spheres[prim], ps.ray, t);
         wl = wavelength_new(ps.hero_nm);
-        int2 info = sc.prim_info[prim];
+        int4 info = sc.prim_info[prim];
         light_index = info.y;
         if (!NAIVE && light_index >= 0) {  // hwss_slow.rs:46-49, swss_slow.rs:45-48
-            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl, MONO);
+            int lp_unused;
+            F4 le = spectrum_evaluate(light_spectrum(sc, (uint32_t)light_index, lp_unused), wl, MONO);
             if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
             else ps.rad = ps.rad + ps.thr * le;
         }
         if (info.x < 0) alive = false;  // no material: break
         else {
-            bsdf = sc.bsdfs[info.x];
-            if (CLS == IRIS_CLS_LAMBERT_CONSTANT) bsdf.kind = IRIS_BSDF_LAMBERTIAN;
+            // Lambertian/constant class: everything the bounce needs of the material came with prim_info (one 16-byte load beside
+            // the sphere's) instead of the chain prim_info -> bsdfs -> spec_over_pi, three dependent round trips
+            if (CLS == IRIS_CLS_LAMBERT_CONSTANT) bsdf = iris_bsdf{IRIS_BSDF_LAMBERTIAN, 0u, 0u, __int_as_float(info.z), 0.0f};
+            else bsdf = sc.bsdfs[info.x];
         }
     }
     if (alive) cnt.bounces++;
@@ -1573,7 +1587,8 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
 
     if (NAIVE) {
         if (alive && ps.bounce == 0u && light_index >= 0) {  // hwss_naive.rs:51-58, swss_naive.rs:50-55
-            F4 le = spectrum_evaluate(sc.spectra[sc.lights[light_index].spectrum], wl, MONO);
+            int lp_unused;
+            F4 le = spectrum_evaluate(light_spectrum(sc, (uint32_t)light_index, lp_unused), wl, MONO);
             if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
             else ps.rad = ps.rad + ps.thr * le;
         }
@@ -1612,10 +1627,8 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
                 facing_forward = dot(dir, hit.normal) > 0.0f;
                 want1 = light_pdf > 0.0f && facing_forward != hit.back_face;
             } else {
-                iris_light l = sc.lights[light_idx];
-                light_prim = (int)l.prim;
-                light_emission = spectrum_evaluate(sc.spectra[l.spectrum], wl, MONO);
-                light_sphere = sc.spheres[light_prim];
+                light_emission = spectrum_evaluate(light_spectrum(sc, light_idx, light_prim), wl, MONO);
+                light_sphere = sc.light_rec[3u * light_idx];
                 sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf, TRIG_PIN);
                 shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
                 facing_forward = dot(light_pos - hit.point, hit.normal) > 0.0f;

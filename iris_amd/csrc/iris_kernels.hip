@@ -974,7 +974,7 @@ struct iris_ctx {
     bool have_scene = false;
     bool scene_is_lambert_constant = false;
     SceneDev sc = {};
-    void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr, *d_spec_over_pi = nullptr, *d_prim_kind = nullptr;
+    void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr, *d_spec_over_pi = nullptr, *d_prim_kind = nullptr, *d_light_rec = nullptr;
     uint32_t *d_xq = nullptr, *d_stack_hi = nullptr, *d_park = nullptr;
     size_t park_words = 0;
     unsigned char *d_sky = nullptr;
@@ -1447,7 +1447,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_pools(c);
-    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind);
+    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind); dev_free(c->d_light_rec);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     dev_free(c->d_up_coeff); dev_free(c->d_up_scale);
@@ -1545,28 +1545,51 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
         em = nullptr;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind);
+    dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind); dev_free(c->d_light_rec);
     c->d_spec_over_pi = nullptr;
     c->d_prim_kind = nullptr;
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     c->d_env_texels = c->d_env_func = c->d_env_cond = c->d_env_marg = nullptr;
-    c->d_spheres = c->d_prim_info = c->d_bsdfs = c->d_spectra = c->d_lights = nullptr;
+    c->d_spheres = c->d_prim_info = c->d_bsdfs = c->d_spectra = c->d_lights = c->d_light_rec = nullptr;
     c->d_bvh_nodes = c->d_bvh_spheres = c->d_bvh_prim = nullptr;
     c->sc = SceneDev{};
     c->have_scene = false;
-    std::vector<int2> info(s->n_prims);
-    for (uint32_t i = 0; i < s->n_prims; i++) info[i] = make_int2(s->prim_material[i], s->prim_light[i]);
+    // per primitive: (material, light, albedo / PI of a Lambertian material over a constant spectrum -- lambertian.rs:30, one IEEE
+    // division, formed here once -- else 0, 0)
+    std::vector<int4> info(s->n_prims);
+    for (uint32_t i = 0; i < s->n_prims; i++) {
+        float over_pi_i = 0.0f;
+        const int m = s->prim_material[i];
+        if (m >= 0 && s->bsdfs[m].kind == IRIS_BSDF_LAMBERTIAN && s->spectra[s->bsdfs[m].spec_a].kind == IRIS_SPEC_CONSTANT)
+            over_pi_i = iris_f32_div(s->spectra[s->bsdfs[m].spec_a].c0, PI_F);
+        int bits;
+        std::memcpy(&bits, &over_pi_i, 4);
+        info[i] = make_int4(m, s->prim_light[i], bits, 0);
+    }
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
         if (e != hipSuccess) return e;
         return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
     HIP_TRY(c, up(&c->d_spheres, s->spheres, sizeof(iris_sphere) * s->n_prims));
-    HIP_TRY(c, up(&c->d_prim_info, info.data(), sizeof(int2) * s->n_prims));
+    HIP_TRY(c, up(&c->d_prim_info, info.data(), sizeof(int4) * s->n_prims));
     HIP_TRY(c, up(&c->d_bsdfs, s->bsdfs, sizeof(iris_bsdf) * s->n_bsdfs));
     HIP_TRY(c, up(&c->d_spectra, s->spectra, sizeof(iris_spectrum) * s->n_spectra));
     HIP_TRY(c, up(&c->d_lights, s->lights, sizeof(iris_light) * s->n_lights));
+    {
+        std::vector<float4> rec(3 * (size_t)s->n_lights);
+        auto as_float = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+        for (uint32_t i = 0; i < s->n_lights; i++) {
+            const iris_sphere &sp = s->spheres[s->lights[i].prim];
+            const iris_spectrum &e = s->spectra[s->lights[i].spectrum];
+            rec[3 * i] = make_float4(sp.cx, sp.cy, sp.cz, sp.r);
+            rec[3 * i + 1] = make_float4(as_float(s->lights[i].prim), as_float(e.kind), e.c0, e.c1);
+            rec[3 * i + 2] = make_float4(e.c2, e.hdr, 0.0f, 0.0f);
+        }
+        HIP_TRY(c, up(&c->d_light_rec, rec.data(), sizeof(float4) * rec.size()));
+        c->sc.light_rec = (const float4 *)c->d_light_rec;
+    }
     std::vector<float> over_pi(std::max<uint32_t>(s->n_spectra, 1u), 0.0f);
     for (uint32_t i = 0; i < s->n_spectra; i++) over_pi[i] = iris_f32_div(s->spectra[i].c0, PI_F);  // lambertian.rs:30: albedo / PI, one IEEE division
     HIP_TRY(c, up(&c->d_spec_over_pi, over_pi.data(), sizeof(float) * over_pi.size()));
@@ -1576,7 +1599,7 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     HIP_TRY(c, up(&c->d_prim_kind, kind.data(), kind.size()));
     c->sc.prim_kind = (const unsigned char *)c->d_prim_kind;
     c->sc.spheres = (const float4 *)c->d_spheres;
-    c->sc.prim_info = (const int2 *)c->d_prim_info;
+    c->sc.prim_info = (const int4 *)c->d_prim_info;
     c->sc.bsdfs = (const iris_bsdf *)c->d_bsdfs;
     c->sc.spectra = (const iris_spectrum *)c->d_spectra;
     c->sc.lights = (const iris_light *)c->d_lights;
