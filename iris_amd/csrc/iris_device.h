@@ -195,6 +195,15 @@ IRIS_DEV double trig_kcos(double r, bool pin) {
 }
 // sin and cos of the same argument share the reduction and both kernels.
 IRIS_DEV void iris_sincos(float x, float &s_out, float &c_out, bool pin = true) {
+#if IRIS_RELAXED
+    // relaxed build: the hardware's sine and cosine (arguments in revolutions; absolute error about 1e-6) instead of ~45 binary64
+    // instructions.  Every caller passes an angle in [-pi, 2 pi] and normalises the direction it builds from the result.
+    (void)pin;
+    const float rev = x * 0.15915494309189535f;
+    s_out = __builtin_amdgcn_sinf(rev);
+    c_out = __builtin_amdgcn_cosf(rev);
+    return;
+#endif
     double xd = (double)x;
     if (!(__builtin_fabs(xd) < 1.0e5)) { s_out = x - x; c_out = x - x; return; }
     int q;
