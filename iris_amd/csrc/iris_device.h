@@ -920,6 +920,12 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &
 #ifndef IRIS_POOL_MIN_ROUNDS
 #define IRIS_POOL_MIN_ROUNDS 6u // ... but not before this many rounds, so that parked rays move on in every pass
 #endif
+#ifndef IRIS_POOL_INNER_PCT
+#define IRIS_POOL_INNER_PCT 50u // a round steps through inner nodes when at least this share of the walking lanes is at one, else through leaves (35 .. 80 measure within 2 %)
+#endif
+#ifndef IRIS_POOL_INNER_REPS
+#define IRIS_POOL_INNER_REPS 3  // inner-node steps per such round: the round's ballots, counts and branch are paid once for all of them (1: 154.7 ms, 2: 147.2, 3: 145.1, 4: 146.2, 8: 147.8 on config D)
+#endif
 #define IRIS_WALK_WORDS (10u + IRIS_BVH_STACK)  // parked walker: o, d, closest t, closest, node reference, (slot, kind, stack depth), stack
 IRIS_DEV uint32_t lanes_below(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -1053,14 +1059,8 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
         // ---- one kind of step per round, the kind more lanes are waiting for: inner nodes or leaves ----
         const bool at_inner = have && (ref >> 29) == 0u;
         const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
-#ifndef IRIS_POOL_INNER_PCT
-#define IRIS_POOL_INNER_PCT 50u
-#endif
         if (100u * n_inner >= IRIS_POOL_INNER_PCT * n_have) {
             IRIS_POOL_STAT(4, 1ull); IRIS_POOL_STAT(5, (unsigned long long)n_inner);
-#ifndef IRIS_POOL_INNER_REPS
-#define IRIS_POOL_INNER_REPS 3
-#endif
 #pragma unroll
             for (int rep = 0; rep < IRIS_POOL_INNER_REPS; rep++)
             if (have && (ref >> 29) == 0u) {
