@@ -525,6 +525,28 @@ def test_hierarchy_never_culls_what_the_f32_sphere_test_reports(gpu, gpu_list, i
     assert np.array_equal(bits(gpu.render_film(r)), bits(want))
 
 
+@pytest.mark.parametrize("specialize", [1, 0])
+def test_every_leaf_size_gives_the_list_scan_film(gpu_list, specialize):
+    """Option bvh_leaf (spheres per leaf, 1..7; default 2): the tree's shape changes what is tested, never what is found.  Films
+    through the pooled traversal (Lambertian/constant class) and through the general class's own traversal (specialize=0) equal
+    the list scan's bit for bit; rays and bounces too (sphere_tests counts the tests made and differs by design)."""
+    import iris_amd
+    from iris_amd import Render
+    scene = make("s2_small")
+    gpu_list.upload(scene)
+    r = Render(96, 64, 6, scene)
+    want = gpu_list.render_film(r)
+    ws = gpu_list.stats()
+    for leaf in (1, 2, 3, 4, 7):
+        with iris_amd.HipWavefront(device=0, bvh_leaf=leaf, specialize=specialize) as ctx:
+            ctx.upload(scene)
+            film = ctx.render_film(r)
+            st = ctx.stats()
+            assert st.bvh_depth > 0
+            assert np.array_equal(bits(film), bits(want)), leaf
+            assert (st.samples, st.bounces, st.rays) == (ws.samples, ws.bounces, ws.rays), leaf
+
+
 def test_list_scan_films_of_long_lists(gpu_list, iris_trig):
     """The window-resident (600 spheres) and streamed (2500) list scans inside whole renders."""
     from iris_amd import Render
