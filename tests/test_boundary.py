@@ -20,9 +20,10 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "iris_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int|void|float|uint32_t|size_t)\s*\*?\s*(iris_\w+)\s*\(", header, re.M))
     assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
-    L = C.CDLL(ffi.LIB_PATH)
-    for name in declared:
-        assert hasattr(L, name), name
+    for path in (ffi.LIB_PATH, ffi.LIB_RELAXED_PATH):  # the exact build and the opt-in relaxed build of the same ABI
+        L = C.CDLL(path)
+        for name in declared:
+            assert hasattr(L, name), (path, name)
 
 
 def _c_prototypes(header):
