@@ -1348,8 +1348,12 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.stack_lds_n = reg_stack_lds;
         if (reg && c->sc.n_bvh_nodes) a.sphere_cap = reg_stack_lds * BLOCK * sizeof(uint32_t) / sizeof(float4);  // LDS for the first levels only
         a.work_cursor = ws.work_cursor;
-        // a run: 2048 items, less for small launches so that every wave still gets several (the tail is one run per wave)
-        a.work_run = c->work_run ? (uint32_t)c->work_run : std::min<uint32_t>(2048u, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
+        // a run: 2048 items for the Lambertian list kernel (512 .. 4096 measure alike there), 512 for the general classes and 256 under
+        // a hierarchy, where an item costs several times as much and the launch's tail -- one run per wave -- weighs accordingly
+        // (config D: 4096 125.5 ms, 2048 119.8, 1024 117.1, 512 115.9, 256 115.4, 64 116.1); less for small launches so that every wave
+        // still gets several
+        const uint32_t run_cap = c->sc.n_bvh_nodes ? 256u : (c->scene_class == IRIS_CLS_LAMBERT_CONSTANT ? 2048u : 512u);
+        a.work_run = c->work_run ? (uint32_t)c->work_run : std::min<uint32_t>(run_cap, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
         if (reg) HIP_TRY(c, hipMemsetAsync(ws.work_cursor, 0, sizeof(unsigned long long), stream));
         a.x_park_max = (uint32_t)c->x_park_max;
         a.x_fire = (uint32_t)c->x_fire;
