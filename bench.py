@@ -32,13 +32,90 @@ PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md, HBM3E bandwidth
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
-def measured_traffic(key):
+def measured_profile(key):
+    """The committed PMC profile of a workload (profiles/traffic.json, written by tools/summarize_profile.py), or {}."""
     try:
         with open(TRAFFIC_FILE) as f:
-            e = json.load(f).get(key)
+            return json.load(f).get(key) or {}
+    except (OSError, ValueError):
+        return {}
+
+
+def measured_traffic(key):
+    e = measured_profile(key)
+    try:
         return (float(e["bytes_per_launch"]), e["source"]) if e else (None, None)
-    except (OSError, ValueError, KeyError):
+    except KeyError:
         return None, None
+
+
+def workload_key(scene, width, height, spp, opts=()):
+    return "%s_%dx%dx%d%s" % (scene, width, height, spp, "".join("_%s=%d" % kv for kv in sorted(dict(opts).items())))
+
+
+def make_scene(iris_amd, name, env_size):
+    scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[name[:2]]()
+    if name.endswith("env"):  # procedural HDR sky through the RGB -> spectrum table (a data fixture; tools/rgb2spec_opt.c makes it)
+        table = iris_amd.UpsampleTable(os.path.join(ROOT, "tests", "golden", "srgb_res16.coeff"))
+        scene.env_map = iris_amd.EnvMap.sky(table, env_size, env_size)
+    return scene
+
+
+def roofline_of(iris_amd, scene, key, width, height, steps, st, kernel_ms, flops):
+    """The `roofline` object of one workload from the exact device counters and the HIP-event kernel time of `steps` steps."""
+    n_launches = steps * max(1, st.chunks)
+    secs = kernel_ms * 1e-3
+    # flops the reference's algorithm executes for this film, and the part of them the kernel executes: the samples of
+    # pixels that the sky mask proves black are never traced (their camera sample and primary scan are not run)
+    flops_skipped = steps * (F_CAM + F_ISECT * len(scene.primitives)) * st.sky_samples
+    executed = (flops - flops_skipped) / secs / 1e12 if secs > 0 else 0.0
+    reference_work = flops / secs / 1e12 if secs > 0 else 0.0
+    prof = measured_profile(key)
+    traffic, traffic_source = measured_traffic(key)
+    # SURVEY section 8(d): algorithmic bytes = the film (12 B per pixel) + the scene read once (16 B per sphere)
+    algorithmic_bytes = 12.0 * width * height + 16.0 * len(scene.primitives)
+    return {"bound": "valu", "achieved": round(executed, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(executed / PEAK_FP32_VALU_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes": algorithmic_bytes,
+            "traffic_over_algorithmic": round(traffic / algorithmic_bytes, 1) if traffic else None,
+            "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / n_launches, 3),
+            "flop_model": "120*samples + 27*sphere_tests + 444*bounces over exact device counters (= the oracle's), minus "
+                          "(120 + 27*n_prims)*sky_samples for the camera samples the sky mask proves black and never traces",
+            "achieved_reference_work": round(reference_work, 3),
+            "frac_reference_work": round(reference_work / PEAK_FP32_VALU_TFLOPS, 4),
+            # read from the committed rocprofv3 PMC profile of this workload (profiles/, like `traffic`); null without one
+            "valu_busy": prof.get("valu_busy"), "lane_utilisation": prof.get("lane_utilisation"),
+            "wave_cycles_waiting": prof.get("wave_cycles_waiting"), "counters_source": prof.get("counters_source")}
+
+
+def other_config(iris_amd, torch, name, label, width, height, spp, steps, env_size, device):
+    """One more BASELINE configuration on this GPU, measured like the headline: inputs resident, `steps` timed passes."""
+    scene = make_scene(iris_amd, name, env_size)
+    max_depth = 32 if name.startswith("s3") else iris_amd.scene.MAX_DEPTH
+    render = iris_amd.Render(width, height, spp, scene, max_depth=max_depth)
+    film = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda")
+    with iris_amd.HipWavefront(device=device) as gpu:
+        gpu.upload(scene)
+        gpu.render_film_device(render, film.data_ptr())  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms, flops, st = 0.0, 0.0, None
+        for _ in range(steps):
+            gpu.render_film_device(render, film.data_ptr())
+            st = gpu.stats()
+            kernel_ms += st.kernel_ms
+            flops += algorithmic_flops(st)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    return {"workload": label, "metric": "Msamples/s", "value": round(width * height * spp * steps / 1e6 / elapsed, 2),
+            "value_traced_only": round((st.samples - st.sky_samples) * steps / 1e6 / elapsed, 2),
+            "ms_per_step": round(elapsed * 1e3 / steps, 3), "steps": steps, "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel],
+            "kernel_ms_per_launch": round(kernel_ms / (steps * max(1, st.chunks)), 3),
+            "roofline": roofline_of(iris_amd, scene, workload_key(name, width, height, spp), width, height, steps, st, kernel_ms, flops),
+            "rays_per_s": round((st.rays - st.sky_samples) / (kernel_ms / steps * 1e-3), 1) if kernel_ms else None,
+            "counters_per_step": {"samples": st.samples, "bounces": st.bounces, "rays": st.rays, "sphere_tests": st.sphere_tests,
+                                  "bvh_depth": st.bvh_depth, "sky_samples": st.sky_samples}}
 
 
 def algorithmic_flops(st):
@@ -104,6 +181,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-c", action="store_true", help="skip the extra strong-scaling leg (BASELINE config C: 3840x2160 at 4096 spp in all)")
     ap.add_argument("--no-relaxed", action="store_true", help="skip the extra leg on the opt-in relaxed-arithmetic build (reported beside `value`, never as it)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extra single-GPU legs on BASELINE configs D and E, S3 and the default scene under the sky")
     ap.add_argument("--multi-kernel", action="store_true", help="launch the two stages as separate kernels")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="iris_ctx_set_option tuning knob (repeatable)")
     args = ap.parse_args()
@@ -135,10 +213,7 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
-    scene = {"s1": iris_amd.Scene.dummy, "s2": iris_amd.Scene.many_spheres, "s3": iris_amd.Scene.glossy_dielectric}[args.scene[:2]]()
-    if args.scene.endswith("env"):  # procedural HDR sky through the RGB -> spectrum table (a data fixture; tools/rgb2spec_opt.c makes it)
-        table = iris_amd.UpsampleTable(os.path.join(ROOT, "tests", "golden", "srgb_res16.coeff"))
-        scene.env_map = iris_amd.EnvMap.sky(table, args.env_size, args.env_size)
+    scene = make_scene(iris_amd, args.scene, args.env_size)
     max_depth = 32 if args.scene.startswith("s3") else iris_amd.scene.MAX_DEPTH
     spp_total = args.spp * world
     render = iris_amd.Render(args.width, args.height, spp_total, scene, max_depth=max_depth)
@@ -243,20 +318,10 @@ def main():
                    "build": "libiris_hip_relaxed.so (-DIRIS_RELAXED=1)"}
         rgpu.close()
 
-    workload_key = "%s_%dx%dx%d%s" % (args.scene, args.width, args.height, args.spp, "".join("_%s=%d" % kv for kv in sorted(opts.items())))
     if rank == 0:
         samples_per_step = args.width * args.height * spp_total
         value = samples_per_step * args.steps / 1e6 / elapsed
-        n_launches = args.steps * max(1, st.chunks)
-        secs = kernel_ms * 1e-3
-        # flops the reference's algorithm executes for this film, and the part of them the kernel executes: the samples of
-        # pixels that the sky mask proves black are never traced (their camera sample and primary scan are not run)
-        flops_skipped = args.steps * (F_CAM + F_ISECT * len(scene.primitives)) * st.sky_samples
-        executed = (flops - flops_skipped) / secs / 1e12 if secs > 0 else 0.0
-        reference_work = flops / secs / 1e12 if secs > 0 else 0.0
-        traffic, traffic_source = measured_traffic(workload_key)
-        # algorithmic bytes = the film (12 B per pixel) + the scene read once (16 B per sphere)
-        algorithmic_bytes = 12.0 * args.width * args.height + 16.0 * len(scene.primitives)
+        roofline = roofline_of(iris_amd, scene, workload_key(args.scene, args.width, args.height, args.spp, opts), args.width, args.height, args.steps, st, kernel_ms, flops)
         line = {
             "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True,
@@ -270,16 +335,10 @@ def main():
                        "ranks": dist.get_world_size() if world > 1 else 1},
             # rank 0's path-tracing kernel, timed with HIP events on its own stream inside the library.  achieved/frac count
             # the flops of the work the kernel EXECUTES; achieved_reference_work prices everything the reference would execute
-            "roofline": {"bound": "valu", "achieved": round(executed, 3), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(executed / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes": algorithmic_bytes,
-                         "traffic_over_algorithmic": round(traffic / algorithmic_bytes, 1) if traffic else None,
-                         "kernel": "%s<HwssNaive>" % iris_amd.ffi.KERNEL_NAMES[st.kernel], "kernel_ms_per_launch": round(kernel_ms / n_launches, 3),
-                         "flop_model": "120*samples + 27*sphere_tests + 444*bounces over exact device counters (= the oracle's), minus "
-                                       "(120 + 27*n_prims)*sky_samples for the camera samples the sky mask proves black and never traces",
-                         "achieved_reference_work": round(reference_work, 3),
-                         "frac_reference_work": round(reference_work / PEAK_FP32_VALU_TFLOPS, 4)},
+            # samples the kernel traces per second: those of pixels the sky mask proves black are counted in `value` (their result,
+            # zero, is the reference's bit for bit) but cost nothing; with an environment map the mask is off and the two are equal
+            "value_traced_only": round((st.samples - st.sky_samples) * world * args.steps / 1e6 / elapsed, 2),
+            "roofline": roofline,
             # the second kernel of a step, HBM-bound: it reads the 12-byte result of every stored sample once and writes the film
             "roofline_resolve": {"bound": "hbm", "achieved": round(resolve_bytes / (resolve_ms * 1e-3) / 1e9, 1) if resolve_ms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -297,6 +356,18 @@ def main():
             line["config_c_strong"] = config_c
         if relaxed is not None:
             line["relaxed_mode"] = relaxed
+        # ---- fourth leg, one GPU, default flags only: the other BASELINE configurations, two timed steps each, so that the
+        # driver's record carries them (config D: 10k spheres; config E: glossy/dielectric under the HDR sky, depth 32; S3 without
+        # the sky; the default scene under the sky, where no sample is skipped)
+        if world == 1 and args.scene == "s1" and not opts and not args.no_other_configs and not args.multi_kernel:
+            del film
+            line["other_configs"] = {
+                name: other_config(iris_amd, torch, name, label, args.width, args.height, spp, 2, args.env_size, local_rank)
+                for name, label, spp in (
+                    ("s2", "BASELINE config D: synthetic 10k-sphere scene (hierarchy), 64 spp", 64),
+                    ("s3env", "BASELINE config E: glossy/dielectric scene under the %dx%d HDR sky, 256 spp, max_depth 32" % (args.env_size, args.env_size), 256),
+                    ("s3", "glossy/dielectric scene without the sky, 256 spp, max_depth 32", 256),
+                    ("s1env", "default scene under the %dx%d HDR sky (BASELINE's wording of configs A-C), 256 spp" % (args.env_size, args.env_size), 256))}
         if world == 1 and not args.no_cpu_baseline:
             n_threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
             line["cpu_baseline"] = cpu_baseline(n_threads)

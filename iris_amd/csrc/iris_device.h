@@ -1532,33 +1532,45 @@ IRIS_DEV void path_miss(const SceneDev &sc, PathState &ps) {
     if (HWSS) ps.rad = ps.rad + (ps.thr * le) * balance_heuristic_1(ps.ppdf);
     else ps.rad = ps.rad + ps.thr * le;
 }
-// What shade_bounce<.., DEFER = true> leaves undone (Lambertian/constant class under a hierarchy, where the four wavelengths
-// carry one value): the light-sample visibility query of direct_light (hwss_naive.rs:115-123) is handed back to the caller, who
-// runs it in the wave's ray pool together with the extension rays (bvh_pooled) and then calls apply_deferred, which performs
-// the additions of hwss_naive.rs:131-133, :148-151, :155 and :61-62 in the reference's order on the values kept here.
+// What shade_bounce<.., DEFER != 0> leaves undone (Lambertian/constant class under a hierarchy, where the four wavelengths
+// carry one value): visibility queries of direct_light are handed back to the caller, who has them traced elsewhere and then
+// calls apply_deferred, which performs the additions of hwss_naive.rs:131-133, :148-151, :155 and :61-62 in the reference's
+// order on the values kept here.
+//   DEFER == 1 (pooled traversal of k_regwave): the light-sample query (hwss_naive.rs:115-123) goes to the wave's ray pool; the
+//              BSDF-sampled ray's question is still answered inside shade_bounce.
+//   DEFER == 2 (queue kernels, k_wfq_*): both go out -- shade_bounce compiles no traversal code at all.  The BSDF-sampled ray's
+//              question "is the chosen light the closest hit?" (scene.rs:151-166) becomes: the light's own sphere is hit at
+//              limit2 > 0 (tested here), and no sphere is preferred to that hit (`ray2` up to `limit2`, ties broken against
+//              primitive `tie2`); its contribution c2 is formed here on the assumption that the answer is yes.
 struct Deferred {
     bool pending;      // there is a direct-light term to add (the hit has a material)
     bool want1;        // the light sample passed the pre-checks: its visibility query is `ray1` up to `limit1`
-    bool has2;         // the BSDF-sampled ray reached the chosen light: `c2` counts
+    bool has2;         // DEFER 1: the BSDF-sampled ray reached the chosen light: `c2` counts.  DEFER 2: it reached the light's sphere: `c2` counts unless the query finds an occluder
     Ray ray1;
     float limit1;
     float c1, c2;      // the two MIS-weighted contributions (each the same for the four wavelengths)
     float thr, weight; // throughput before this bounce's update, light pick weight
+    // DEFER 2 only
+    Ray ray2;
+    float limit2;
+    int tie2;
+    uint32_t spec_tests2;  // sphere tests made while forming c2 (Sphere::pdf from inside the light): counted only if c2 counts
 };
-IRIS_DEV void apply_deferred(const Deferred &df, bool occluded1, PathState &ps) {
+IRIS_DEV void apply_deferred(const Deferred &df, bool occluded1, PathState &ps, bool occluded2 = false) {
     if (!df.pending) return;
     const bool visible = df.want1 && !occluded1 && __builtin_inff() > df.limit1;  // scene.rs:147-148: closest_t > target_t - eps
     F4 direct = splat(0.0f);
     if (visible) direct = direct + splat(df.c1);
-    if (df.has2) direct = direct + splat(df.c2);
+    if (df.has2 && !occluded2) direct = direct + splat(df.c2);
     ps.rad = ps.rad + splat(df.thr) * (direct * df.weight);
 }
-template <int INTEG, int CLS, bool DEFER = false>
+template <int INTEG, int CLS, int DEFER = 0>
 IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, DrawRing ring, bool active,
                            PathState &ps, int prim, float t, Counters &cnt, Deferred *df = nullptr) {
     static_assert(!DEFER || CLS == IRIS_CLS_LAMBERT_CONSTANT, "the deferred form keeps one value for the four wavelengths");
     if (DEFER && active) { df->pending = false; df->want1 = false; df->has2 = false;  // (lanes that wait for their rays keep what they deferred)
-        df->limit1 = __builtin_inff(); df->c1 = 0.0f; df->c2 = 0.0f; df->thr = 0.0f; df->weight = 0.0f; }
+        df->limit1 = __builtin_inff(); df->c1 = 0.0f; df->c2 = 0.0f; df->thr = 0.0f; df->weight = 0.0f;
+        if (DEFER == 2) { df->limit2 = __builtin_inff(); df->tie2 = 0x7fffffff; df->spec_tests2 = 0u; } }
     constexpr bool HWSS = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_HWSS_SLOW);
     constexpr bool NAIVE = (INTEG == IRIS_INT_HWSS_NAIVE || INTEG == IRIS_INT_SWSS_NAIVE);
     // all draws of this bounce, generated for the whole wave at once: light pick 1 + light point 2 + BSDF 2 + BSDF 2 +
@@ -1712,7 +1724,15 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         float st2 = __builtin_inff();
         int sp2 = -1;
         bool on_light_bvh = false;  // the closest hit of the BSDF-sampled ray is the chosen light (the map: nothing is hit)
-        if (st.bvh) {
+        if (DEFER == 2) {
+            // the light's own sphere here (one test, which most rays fail and are done); whether anything is preferred to that hit is
+            // the caller's query
+            if (want2) {
+                const float limit = sphere_hit_t(stage_sphere(light_sphere), shadow2, len_squared(shadow2.d));
+                cnt.sphere_tests++;  // the test of the light's own sphere is made whether or not it hits
+                if (limit > 0.0f) { on_light_bvh = true; df->ray2 = shadow2; df->limit2 = limit; df->tie2 = light_prim; }
+            }
+        } else if (st.bvh) {
             // Scene::ray_hits_object (scene.rs:151-166) is used for one thing: `closest primitive == the light's`.  That
             // needs the light's own sphere to be hit -- one test, and most rays fail it and are done -- and then no sphere
             // that the scan would prefer to it: the same visibility query as above, with the light's hit as the limit and
@@ -1735,13 +1755,14 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
         }
         if (want2) {
             cnt.rays++;
-            if (st.bvh ? on_light_bvh : sp2 == light_prim) {
+            if ((DEFER == 2 || st.bvh) ? on_light_bvh : sp2 == light_prim) {
                 float lpdf;
+                unsigned long long pdf_tests = 0ull;
                 if (ENV && env_pick) env_eval(sc, shadow2.d, wl, light_emission, lpdf);
-                else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, cnt.sphere_tests);
+                else lpdf = sphere_pdf(light_sphere, hit, shadow2.d, DEFER == 2 ? pdf_tests : cnt.sphere_tests);
                 float mis_weight = HWSS ? balance_heuristic_2(bs_pdfs, splat(lpdf)) : fdiv(hero(bs_pdfs), hero(bs_pdfs) + lpdf);
                 const F4 c2 = div4(((mis_weight * light_emission) * bs_values) * bs_cos, hero(bs_pdfs), MONO);
-                if (DEFER) { df->has2 = true; df->c2 = c2.v[0]; }
+                if (DEFER) { df->has2 = true; df->c2 = c2.v[0]; if (DEFER == 2) df->spec_tests2 = (uint32_t)pdf_tests; }
                 else direct = direct + c2;
             }
         }

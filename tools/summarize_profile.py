@@ -53,14 +53,41 @@ for k, cs in agg.items():
 if len(sys.argv) > 3 and sys.argv[2] != "-":
     import json
     key, dest = sys.argv[2], sys.argv[3]
-    best = max((k for k in agg if k.startswith("k_") and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]),
-               key=lambda k: agg[k].get("SQ_BUSY_CYCLES", 0.0), default=None)
-    if best:
-        fetch = agg[best]["FETCH_SIZE"] / max(1, len(ndisp[(best, "FETCH_SIZE")])) * 1024.0
-        write = agg[best]["WRITE_SIZE"] / max(1, len(ndisp[(best, "WRITE_SIZE")])) * 1024.0
+    # The path-tracing stage of one bench step is one dispatch of k_regwave / k_wavefront, or many dispatches of the queue kernels
+    # (k_wfq_*); everything is reported PER STEP: counter sums over the stage's kernels divided by the number of steps the pass
+    # ran, which is the number of k_resolve dispatches (one per step and chunk).
+    stage = [k for k in agg if k.startswith("k_") and not k.startswith(("k_resolve", "k_sky_mask", "k_upsample", "k_dbg"))]
+
+    def per_step(counter):
+        n_steps = max(1, len(ndisp[("k_resolve", counter)]))
+        return sum(agg[k].get(counter, 0.0) for k in stage) / n_steps, n_steps
+
+    if stage and all(any(c in agg[k] for k in stage) for c in ("FETCH_SIZE", "WRITE_SIZE")):
+        fetch, write = per_step("FETCH_SIZE")[0] * 1024.0, per_step("WRITE_SIZE")[0] * 1024.0
+        best = max(stage, key=lambda k: agg[k].get("SQ_BUSY_CYCLES", 0.0))
         entry = {key: {"bytes_per_launch": round(2.0 * fetch + write), "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write),
-                       "kernel": best, "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `%s`, per dispatch; "
-                                                 "FETCH_SIZE doubled (gfx950 counts 128-byte read requests as 64 bytes)" % " ".join(sys.argv[4:] or ["bench.py"])}}
+                       "kernel": best if len(stage) == 1 else " + ".join(sorted(stage)),
+                       "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `%s`, per %s; "
+                                 "FETCH_SIZE doubled (gfx950 counts 128-byte read requests as 64 bytes)" %
+                                 (" ".join(sys.argv[4:] or ["bench.py"]), "dispatch" if len(stage) == 1 else "step (all dispatches of the stage's kernels)")}}
+        # issue-side figures of the same stage, recomputable from the counters printed above:
+        #   lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+        #   wave-cycles waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES
+        #   VALU busy = SQ_INSTS_VALU x 3 cycles (mean issue cost of this instruction mix, DESIGN.md "Instruction prices") /
+        #               (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs summed over the stage's dispatches
+        e = entry[key]
+        tv, av = per_step("SQ_THREAD_CYCLES_VALU")[0], per_step("SQ_ACTIVE_INST_VALU")[0]
+        wa, wc = per_step("SQ_WAIT_ANY")[0], per_step("SQ_WAVE_CYCLES")[0]
+        iv, gui = per_step("SQ_INSTS_VALU")[0], per_step("GRBM_GUI_ACTIVE")[0]
+        if av > 0:
+            e["lane_utilisation"] = round(tv / (64.0 * av), 4)
+        if wc > 0:
+            e["wave_cycles_waiting"] = round(wa / wc, 4)
+        if gui > 0:
+            e["valu_busy"] = round(iv * 3.0 / (1024.0 * gui / 8.0), 4)
+            e["valu_insts_per_step"] = round(iv)
+        e["counters_source"] = "rocprofv3 --pmc passes of the same command (tools/profile_gpu.sh): lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU); " \
+                               "wave_cycles_waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu_busy = SQ_INSTS_VALU x 3 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
         json.dump(entry, open(dest, "w"), indent=1)
         print("== traffic entry ==")
         print(json.dumps(entry))
