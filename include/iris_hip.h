@@ -150,7 +150,8 @@ typedef struct {
 enum iris_kernel_variant {
     IRIS_KERNEL_POOL_FUSED = 0,   /* k_wavefront: pool/queue stages in one persistent kernel */
     IRIS_KERNEL_POOL_STAGES = 1,  /* k_stage_gen_extend + k_stage_shade launched alternately */
-    IRIS_KERNEL_REGISTER = 2      /* k_regwave: path state in registers, per-wave queue of primary hits in LDS */
+    IRIS_KERNEL_REGISTER = 2,     /* k_regwave: path state in registers, per-wave queue of primary hits in LDS */
+    IRIS_KERNEL_QUEUES = 3        /* k_wfq_shade + k_wfq_trace launched alternately over path-state and ray queues in HBM */
 };
 
 /* One traced camera sample, for stage-level parity tests (iris_dbg_trace). */
@@ -183,7 +184,11 @@ const char *iris_last_error(const iris_ctx *ctx);
  *   "mode"            0: choose by scene (default: register-resident kernel for up to 64 spheres and for scenes
  *                     with a hierarchy, pool/queue kernels for longer lists scanned sphere by sphere);
  *                     1: pool/queue kernels (path state in HBM/L2, rays compacted before every scan);
- *                     2: register-resident kernel (needs the sphere list to fit the LDS window, or a hierarchy)
+ *                     2: register-resident kernel (needs the sphere list to fit the LDS window, or a hierarchy);
+ *                     3: queue kernels (shading and traversal as separate kernels over path-state and ray queues in HBM;
+ *                     needs a hierarchy and a scene of Lambertian BSDFs over constant spectra, for which mode 0 chooses it)
+ *   "wfq_slots"       queue kernels: path-state slots in all (default 4194304; a multiple of 256)
+ *   "wfq_pipes"       queue kernels: independent pipelines on streams of their own that share the slots (1..4, default 2)
  *   "work_run"          register-resident kernel: items a wave claims at a time from the launch's counter (0 = auto, default)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 8: at least what a CU holds; items are claimed from one global counter)
  *   "bvh_min_prims"   scenes with at least this many spheres get a bounding-volume hierarchy at upload and the

@@ -1122,6 +1122,159 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
 #endif
 }
 
+// ---- the same queries as a kernel of their own: rays in a queue in HBM, results in an array beside it (k_wfq_trace) ----
+// The traversal is bound by the latency of dependent L2 reads and by lanes that leave the tree at different times; both want many
+// more rays in flight than a kernel that also shades can hold (168 registers, three waves per SIMD).  So the queue kernels give it
+// a kernel of its own: nothing but this loop, small enough for eight waves per SIMD, every lane taking the next ray of the queue
+// when it has finished one.  A ray is two float4: (o, cull_t) and (d, word); word = WFQ_DONE: already answered by the producer (it
+// tests the spheres outside the tree and the root box with its whole wave busy: wfq_prepare); else bit 31 = any-hit query, low bits
+// = the tie primitive (any-hit) or 1 + the closest primitive so far (closest-hit).  Per ray the steps are bvh_closest's, one for
+// one: same boxes entered, same spheres tested in the same order, so results and test counts are those of every other kernel.
+#define IRIS_WFQ_DONE 0x7fffffffu
+#define IRIS_WFQ_ANY 0x80000000u
+#ifndef IRIS_WFQ_FETCH_MIN
+#define IRIS_WFQ_FETCH_MIN 12u  // idle lanes that make a fetch worth its instructions
+#endif
+#ifndef IRIS_WFQ_INNER_PCT
+#define IRIS_WFQ_INNER_PCT 50u
+#endif
+#ifndef IRIS_WFQ_INNER_REPS
+#define IRIS_WFQ_INNER_REPS 3
+#endif
+IRIS_DEV void wfq_sphere_test(const SceneDev &sc, uint32_t slot, V3 o, V3 d, float a, exact::Recip ya, bool any, int tie, float &cull_t, int &closest) {
+    const float4 sp4 = sc.bvh_spheres[slot];
+    V3 oc = o - v3(sp4.x, sp4.y, sp4.z);
+    float half_b = dot(d, oc);
+    float c = len_squared(oc) - sp4.w;
+    float discrim = half_b * half_b - a * c;
+    if (discrim > 0.0f) {  // sphere.rs:31-35, :53
+        float temp = first_positive_root(half_b, sqrt_x(discrim), a, a_is_unit(a), ya);
+        if (temp > 0.0f) {
+            const int index = (int)sc.bvh_prim[slot];
+            if (any) { if (temp < cull_t || (temp == cull_t && index < tie)) closest = index; }  // bvh_sphere_test_any
+            else if (temp < cull_t || (temp == cull_t && index < closest)) { cull_t = temp; closest = index; }  // bvh_sphere_test
+        }
+    }
+}
+// The producer's part of a ray: the spheres kept out of the tree (tested first, as bvh_closest does) and the root box.  Returns the
+// two float4 of the record; `answered`: the queue kernel has nothing to do (an any-hit query that one of those spheres answers, or a
+// ray that misses the tree), (cull_t, closest) is the result.
+IRIS_DEV void wfq_prepare(const SceneDev &sc, const Ray &ray, bool any, float limit, int tie, float4 &rec_o, float4 &rec_d, bool &answered,
+                          float &cull_t, int &closest, unsigned long long &tests) {
+    const float a = len_squared(ray.d);
+    const exact::Recip ya = exact::recip_for(a);
+    cull_t = limit;
+    closest = -1;
+    for (uint32_t b = 0; b < sc.bvh_big_count; b++) wfq_sphere_test(sc, sc.bvh_big_first + b, ray.o, ray.d, a, ya, any, tie, cull_t, closest);
+    tests += sc.bvh_big_count;
+    answered = any && closest >= 0;
+    if (!answered) {
+        const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
+        answered = !(box_entry(root_lo, root_hi, ray.o, bvh_inv_dir(ray.d), cull_t) < __builtin_inff());
+    }
+    rec_o = make_float4(ray.o.x, ray.o.y, ray.o.z, cull_t);
+    const uint32_t word = answered ? IRIS_WFQ_DONE : (any ? (IRIS_WFQ_ANY | ((uint32_t)tie & 0x7fffffffu)) : (uint32_t)(closest + 1));
+    rec_d = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(word));
+}
+// One wave's share of a queue of n_rays rays: chunks of `claim` consecutive rays from `cursor`, handed to the lanes as they fall idle.
+IRIS_DEV void wfq_trace_wave(const SceneDev &sc, const SphereStage &st, const float4 *__restrict__ rq_o, const float4 *__restrict__ rq_d, uint2 *__restrict__ res,
+                             uint32_t n_rays, uint32_t *cursor, uint32_t claim, unsigned long long &tests) {
+    bool have = false, any = false, more = true;
+    uint32_t my = 0u, ref = 0u, sp = 0u, n_tests = 0u, w_next = 0u, w_lim = 0u;
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f), inv = v3(0.0f, 0.0f, 0.0f);
+    float a = 1.0f, cull_t = 0.0f;
+    exact::Recip ya = {1.0f};
+    int closest = -1, tie = 0;
+    const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
+    const uint32_t root_ref = bvh_ref(root_lo, root_hi);
+    for (;;) {
+        unsigned long long m_have = __ballot(have);
+        uint32_t n_have = (uint32_t)__popcll(m_have);
+        // ---- fetch: lanes without a ray take the next rays of the wave's chunk (a new chunk when that one is used up) ----
+        if (more && (n_have == 0u || 64u - n_have >= IRIS_WFQ_FETCH_MIN)) {
+            if (w_next >= w_lim) {
+                uint32_t start = 0u;
+                if (lanes_below(~0ull) == 0u) start = atomicAdd(cursor, claim);
+                start = __builtin_amdgcn_readfirstlane(start);
+                if (start >= n_rays) more = false;
+                else { w_next = start; w_lim = min(start + claim, n_rays); }
+            }
+            if (more) {
+                const uint32_t n_take = min(64u - n_have, w_lim - w_next), r = lanes_below(~m_have);
+                if (!have && r < n_take) {
+                    my = w_next + r;
+                    const float4 ro = rq_o[my], rd = rq_d[my];
+                    const uint32_t word = __float_as_uint(rd.w);
+                    if (word != IRIS_WFQ_DONE) {
+                        o = v3(ro.x, ro.y, ro.z);
+                        d = v3(rd.x, rd.y, rd.z);
+                        cull_t = ro.w;
+                        any = (word & IRIS_WFQ_ANY) != 0u;
+                        tie = any ? (int)(word & 0x7fffffffu) : 0;
+                        closest = any ? -1 : (int)word - 1;
+                        a = len_squared(d);  // sphere.rs:27
+                        ya = exact::recip_for(a);
+                        inv = bvh_inv_dir(d);
+                        ref = root_ref;
+                        sp = 0u;
+                        have = true;
+                    }
+                }
+                w_next += n_take;
+                m_have = __ballot(have);
+                n_have = (uint32_t)__popcll(m_have);
+            }
+        }
+        if (n_have == 0u) {
+            if (!more) break;
+            continue;
+        }
+        // ---- one kind of step per round, the kind more lanes are waiting for: inner nodes or leaves ----
+        const bool at_inner = have && (ref >> 29) == 0u;
+        const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
+        if (100u * n_inner >= IRIS_WFQ_INNER_PCT * n_have) {
+#pragma unroll
+            for (int rep = 0; rep < IRIS_WFQ_INNER_REPS; rep++)
+            if (have && (ref >> 29) == 0u) {
+                const uint32_t first = ref & 0x1fffffffu;
+                const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
+                const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];
+                const float tl = box_entry(l0, l1, o, inv, cull_t), tr = box_entry(r0, r1, o, inv, cull_t);
+                const bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
+                if (hl || hr) {
+                    const bool left_first = hl && (!hr || tl <= tr);
+                    const uint32_t ref_l = bvh_ref(l0, l1), ref_r = bvh_ref(r0, r1);
+                    if (hl && hr) {
+                        bvh_push(st, sp, left_first ? ref_r : ref_l);
+                        sp++;
+                    }
+                    ref = left_first ? ref_l : ref_r;
+                } else if (sp != 0u) {
+                    sp--;
+                    ref = bvh_pop(st, sp);
+                } else {
+                    have = false;
+                }
+            }
+        } else if (have && !at_inner) {
+            const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
+            for (uint32_t j = 0; j < count; j++) wfq_sphere_test(sc, first + j, o, d, a, ya, any, tie, cull_t, closest);
+            n_tests += count;
+            if (any && closest >= 0) {
+                have = false;
+            } else if (sp != 0u) {
+                sp--;
+                ref = bvh_pop(st, sp);
+            } else {
+                have = false;
+            }
+        }
+        if (!have && ((m_have >> lanes_below(~0ull)) & 1ull) != 0ull)  // this lane held a ray at the top of the round and is done with it
+            res[my] = make_uint2(__float_as_uint(cull_t), (uint32_t)closest);
+    }
+    tests += n_tests;
+}
+
 // Scene::intersection / ray_hits_point / ray_hits_object all reduce to this scan (scene.rs:116-166):
 // closest t > 0 over all primitives in index order, strict '<' so the lowest index wins ties.
 // Must be called by every thread of the workgroup (inactive threads pass active=false) because a

@@ -132,21 +132,23 @@ __device__ __forceinline__ SphereStage stage_spheres(const SceneDev &sc, float4 
     return st;
 }
 
-__device__ __forceinline__ void store_result(const WfArgs &a, uint32_t item, V3 xyz) {
+template <typename Args>
+__device__ __forceinline__ void store_result(const Args &a, uint32_t item, V3 xyz) {
     XyzResult r = {xyz.x, xyz.y, xyz.z};
     a.results[item] = r;
 }
 
-__device__ __forceinline__ void flush_counters(const WfArgs &a, const Counters &c) {
+__device__ __forceinline__ void flush_counters(unsigned long long *counters, const Counters &c) {
     // wave reduction, then one atomic per wave and counter
     unsigned long long v[4] = {c.samples, c.bounces, c.rays, c.sphere_tests};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane_id() == 0u && x) atomicAdd(&a.counters[k], x);
+        if (lane_id() == 0u && x) atomicAdd(&counters[k], x);
     }
 }
+__device__ __forceinline__ void flush_counters(const WfArgs &a, const Counters &c) { flush_counters(a.counters, c); }
 
 __device__ __forceinline__ unsigned long long item_of(const WfArgs &a, uint32_t k);
 
@@ -689,6 +691,237 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     }
 }
 
+// ---- the queue kernels: shading and traversal as separate kernels over path-state and ray queues in HBM ----
+// (hierarchy + Lambertian/constant class: the 10k-sphere configuration; north_star's "separate kernels over SoA ray/path-state
+// queues in HBM").  k_regwave's pooled traversal shares 168 registers and three waves per SIMD with the shading code and runs at
+// half of its lanes; here the traversal is a kernel of its own (k_wfq_trace: nothing but wfq_trace_wave, eight waves per SIMD,
+// every lane taking the next ray of the queue when it has finished one) and so is everything else (k_wfq_shade):
+//   * a path lives in a SLOT: 48 bytes of state (item, bounce + flags, draws, queue position of its extension ray | throughput,
+//     path pdf, radiance, throughput before the last bounce | the two deferred direct-light contributions and the queue positions
+//     of their visibility queries), three 16-byte arrays indexed by slot, read and written in slot order;
+//   * k_wfq_shade visits every slot: a slot whose extension ray came back with a hit adds the deferred direct light of its last
+//     bounce (apply_deferred: the reference's order of additions), shades the next bounce (shade_bounce<.., 2>: no traversal
+//     code) and appends up to three rays to the ray queue -- extension ray, light-sample query, BSDF-sample query; a slot whose
+//     path has ended (miss, absorption, roulette, depth) adds what was deferred, stores the sample's XYZ and starts the next camera
+//     sample of the launch's item counter in the same lane; rays are appended compacted (one atomic per workgroup and pass);
+//   * k_wfq_trace answers the queue: (t, primitive) per ray into the result array beside it, read by the next k_wfq_shade.
+// Two ray queues alternate (pass p reads queue p & 1 and fills the other); the counters a pass needs at zero are cleared by the
+// kernel before it.  The host launches trace/shade pairs in batches and reads the number of live paths after each batch; several
+// pipelines (streams of their own, own slots and queues, one shared item counter) overlap each other's launch tails.
+// Which slot traces an item changes nothing: every result is a function of the item and goes to the item's own result.
+constexpr uint32_t WFQ_DEAD = 0u, WFQ_RAY = 1u, WFQ_FIN = 2u;  // slot state (bits 16-17 of word 1)
+constexpr uint32_t WFQ_F_PENDING = 4u, WFQ_F_WANT1 = 8u, WFQ_F_LIM1BAD = 16u, WFQ_F_HAS2 = 32u, WFQ_F_SPEC2 = 64u;
+constexpr uint32_t WFQ_NONE = 0xffffffffu;
+enum : uint32_t { WFQ_C_NRAYS = 0u, WFQ_C_CURSOR = 2u, WFQ_C_LIVE = 4u, WFQ_C_WORDS = 8u };
+constexpr uint32_t WFQ_STACK_LDS = 8u;  // traversal-stack entries per lane kept in LDS by k_wfq_trace (8 KiB per workgroup)
+
+struct WfqArgs {
+    SceneDev sc;
+    CamDev cam;
+    FrameDev fr;
+    uint4 *st_a;    // item, bounce | (state | flags) << 16, sampler draws consumed, queue position of the extension ray
+    float4 *st_b;   // throughput, path pdf, radiance, throughput before the last bounce (one value for the four wavelengths)
+    float4 *st_c;   // deferred contributions c1, c2; queue positions of the two visibility queries (bits; WFQ_NONE: none)
+    float4 *rq_o[2], *rq_d[2];  // ray queues: (o, cull_t), (d, word) -- wfq_prepare
+    uint2 *res[2];              // per queue position: (t bits, primitive or -1)
+    uint32_t *ctr;              // WFQ_C_*: rays queued [2], trace cursor [2], live paths [2]
+    XyzResult *results;
+    unsigned long long *counters, *work_cursor;
+    uint32_t npix;
+    FastDiv div_npix, div_width;
+    uint32_t s_begin, n_items, n_slots, par, seed_pass;
+    uint32_t *stack_hi;
+    uint32_t stack_lds_n;
+};
+
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8))) k_wfq_trace(WfqArgs a) {
+    extern __shared__ float4 stack_win[];
+    SphereStage st;
+    st.lds = stack_win;
+    st.cap = 0u;
+    st.resident = false;
+    st.bvh = true;
+    st.stack = (uint32_t *)stack_win + threadIdx.x;
+    st.stack_lds_n = a.stack_lds_n;
+    st.stack_hi = a.stack_hi + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    st.stack_hi_stride = gridDim.x * BLOCK;
+    const uint32_t par = a.par;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {  // what the next k_wfq_shade appends to, and the cursor of the next k_wfq_trace
+        a.ctr[WFQ_C_NRAYS + (par ^ 1u)] = 0u;
+        a.ctr[WFQ_C_CURSOR + (par ^ 1u)] = 0u;
+        a.ctr[WFQ_C_LIVE + (par ^ 1u)] = 0u;
+    }
+    const uint32_t n_rays = a.ctr[WFQ_C_NRAYS + par];
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64u);
+    const uint32_t claim = min(512u, max(64u, (n_rays / n_waves) & ~63u));  // small queues are spread over the whole chip
+    unsigned long long tests = 0ull;
+    wfq_trace_wave(a.sc, st, a.rq_o[par], a.rq_d[par], a.res[par], n_rays, &a.ctr[WFQ_C_CURSOR + par], claim, tests);
+    for (int off = 32; off > 0; off >>= 1) tests += __shfl_down(tests, off, 64);
+    if (lane_id() == 0u && tests) atomicAdd(&a.counters[3], tests);
+}
+
+template <int INTEG>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_wfq_shade(WfqArgs a) {
+    __shared__ uint2 sobol_tab[IRIS_SOBOL_LUT_ENTRIES];
+    __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
+    __shared__ uint32_t wg_count[BLOCK / 64][3];
+    __shared__ uint32_t wg_base;
+    stage_tables(sobol_tab);
+    const SobolLds sobol_lds = sobol_tab;
+    DrawRing ring = ring_lds + threadIdx.x;
+    SphereStage st = {};
+    st.bvh = true;  // shade_bounce<.., 2> makes no scan of its own
+    const uint32_t par = a.par, nxt = a.par ^ 1u;
+    const float4 *__restrict__ rq_o = a.rq_o[par], *__restrict__ rq_d = a.rq_d[par];
+    const uint2 *__restrict__ res = a.res[par];
+    Counters cnt = {0u, 0u, 0u, 0u};
+    uint32_t n_live = 0u;
+    const uint32_t n_tiles = (a.n_slots + BLOCK - 1u) / BLOCK, wave = threadIdx.x / 64u;
+    const float inf = __builtin_inff();
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();  // wg_count / wg_base of the last tile have been read (and, the first time, the Sobol table is complete)
+        const uint32_t slot = tile * BLOCK + threadIdx.x;
+        const bool in_range = slot < a.n_slots;
+        uint4 A = make_uint4(0u, 0u, 0u, WFQ_NONE);
+        if (in_range && !a.seed_pass) A = a.st_a[slot];
+        const uint32_t flags = A.y >> 16, state = flags & 3u;
+        const bool is_ray = state == WFQ_RAY, live_in = is_ray || state == WFQ_FIN;
+        float4 B = make_float4(0.0f, 1.0f, 0.0f, 0.0f), C = make_float4(0.0f, 0.0f, __uint_as_float(WFQ_NONE), __uint_as_float(WFQ_NONE));
+        if (live_in) { B = a.st_b[slot]; C = a.st_c[slot]; }
+        // ---- what the rays of the last pass found ----
+        PathState ps;
+        ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
+        ps.thr = splat(0.0f); ps.ppdf = splat(1.0f); ps.rad = splat(0.0f);
+        ps.smp = sampler_new(0u, 0u, 0u, 0u);
+        float t = 0.0f;
+        int prim = -1;
+        bool occ1 = false, occ2 = false;
+        uint32_t item = A.x;
+        if (live_in) {
+            if (is_ray) {
+                const float4 ro = rq_o[A.w], rd = rq_d[A.w];
+                const uint2 r = res[A.w];
+                ps.ray.o = v3(ro.x, ro.y, ro.z);
+                ps.ray.d = v3(rd.x, rd.y, rd.z);
+                t = __uint_as_float(r.x);
+                prim = (int)r.y;
+            }
+            const uint32_t k1 = __float_as_uint(C.z), k2 = __float_as_uint(C.w);
+            if (k1 != WFQ_NONE) occ1 = (int)res[k1].y >= 0;
+            if (k2 != WFQ_NONE) occ2 = (int)res[k2].y >= 0;
+            // the path's identity: everything else about its sampler and wavelength follows from the item (tile.rs:145-147)
+            const uint32_t s_local = fast_div(item, a.div_npix), pix = item - s_local * a.npix;
+            const uint32_t y = fast_div(pix, a.div_width), x = pix - y * a.fr.width;
+            ps.smp = sampler_new(x, y, a.s_begin + s_local, a.fr.seed);
+            ps.hero_nm = gen_golden_ratio(ps.smp) * LAMBDA_RANGE_NM + LAMBDA_MIN_NM;  // wavelength.rs:26-28, as camera_sample
+            ps.smp.draws = A.z;
+            sampler_rewind(ps.smp);  // the ring of this lane holds another path's values
+            ps.bounce = A.y & 0xffffu;
+            ps.thr = splat(B.x); ps.ppdf = splat(B.y); ps.rad = splat(B.z);
+            // the direct light of the bounce shaded in the last pass, now that its queries are back (hwss_naive.rs:61-62)
+            Deferred prev = {};
+            prev.pending = (flags & WFQ_F_PENDING) != 0u;
+            prev.want1 = (flags & WFQ_F_WANT1) != 0u;
+            prev.limit1 = (flags & WFQ_F_LIM1BAD) ? inf : 0.0f;
+            prev.has2 = (flags & WFQ_F_HAS2) != 0u;
+            prev.c1 = C.x; prev.c2 = C.y; prev.thr = B.w; prev.weight = (float)a.sc.n_lights;
+            apply_deferred(prev, occ1, ps, occ2);
+            if (prev.pending && prev.has2 && !occ2 && (flags & WFQ_F_SPEC2)) cnt.sphere_tests++;
+        }
+        // ---- shade the paths whose extension ray found a surface ----
+        const bool hit = is_ray && prim >= 0;
+        Deferred df = {};
+        bool cont = false;
+        if (__ballot(hit) != 0ull) cont = shade_bounce<INTEG, IRIS_CLS_LAMBERT_CONSTANT, 2>(a.sc, st, a.fr, sobol_lds, ring, hit, ps, prim, t, cnt, &df);
+        const bool go_on = hit && cont;
+        bool has_1 = hit && df.want1, has_2 = hit && df.has2;
+        const bool ended_now = hit && !cont && !has_1 && !has_2;  // nothing of this bounce is out: its direct light is complete
+        if (ended_now) apply_deferred(df, false, ps, false);
+        // ---- finished paths: store the sample (tile.rs:159-162), then the lane starts the launch's next camera sample ----
+        const bool ended = (live_in && !hit) || ended_now;
+        if (ended) store_result(a, item, path_xyz<INTEG>(ps));
+        const bool regen = ended || (in_range && a.seed_pass != 0u);
+        bool got = false;
+        Ray ext = ps.ray;
+        if (__ballot(regen) != 0ull) {
+            const unsigned long long mask = __ballot(regen);
+            unsigned long long base = 0ull;
+            if (lane_id() == 0u) base = atomicAdd(a.work_cursor, (unsigned long long)__popcll(mask));
+            const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)base), base_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+            const unsigned long long id = (((unsigned long long)base_hi << 32) | base_lo) + prefix_below(mask);
+            got = regen && id < (unsigned long long)a.n_items;
+            if (got) {
+                item = (uint32_t)id;
+                const uint32_t s_local = fast_div(item, a.div_npix), pix = item - s_local * a.npix;
+                const uint32_t y = fast_div(pix, a.div_width), x = pix - y * a.fr.width;
+                const CamSample cs = camera_sample(a.cam, a.fr, sobol_lds, x, y, a.s_begin + s_local);
+                ext.o = v3(a.cam.px, a.cam.py, a.cam.pz);
+                ext.d = cs.d;
+                cnt.samples++;
+                cnt.rays++;
+            }
+        }
+        if (go_on) cnt.rays++;  // the extension ray (counted by the other kernels when it comes back)
+        // ---- the rays of this pass: the spheres outside the tree and the root box here, with the whole wave busy ----
+        const bool has_e = go_on || got;
+        float4 e_o = {}, e_d = {}, q1_o = {}, q1_d = {}, q2_o = {}, q2_d = {};
+        bool e_ans = false, q1_ans = false, q2_ans = false;
+        float e_t = 0.0f, q1_t = 0.0f, q2_t = 0.0f;
+        int e_p = -1, q1_p = -1, q2_p = -1;
+        if (has_e) wfq_prepare(a.sc, ext, false, inf, 0, e_o, e_d, e_ans, e_t, e_p, cnt.sphere_tests);
+        if (has_1) wfq_prepare(a.sc, df.ray1, true, df.limit1, 0x7fffffff, q1_o, q1_d, q1_ans, q1_t, q1_p, cnt.sphere_tests);
+        if (has_2) wfq_prepare(a.sc, df.ray2, true, df.limit2, df.tie2, q2_o, q2_d, q2_ans, q2_t, q2_p, cnt.sphere_tests);
+        const unsigned long long m_e = __ballot(has_e), m_1 = __ballot(has_1), m_2 = __ballot(has_2);
+        if (lane_id() == 0u) { wg_count[wave][0] = (uint32_t)__popcll(m_e); wg_count[wave][1] = (uint32_t)__popcll(m_1); wg_count[wave][2] = (uint32_t)__popcll(m_2); }
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            uint32_t total = 0u;
+            for (uint32_t w = 0; w < BLOCK / 64u; w++) total += wg_count[w][0] + wg_count[w][1] + wg_count[w][2];
+            wg_base = total ? atomicAdd(&a.ctr[WFQ_C_NRAYS + nxt], total) : 0u;
+        }
+        __syncthreads();
+        uint32_t k_e = WFQ_NONE, k_1 = WFQ_NONE, k_2 = WFQ_NONE;
+        {   // queue order inside the workgroup's share: extension rays of waves 0..3, then the light-sample queries, then the others
+            uint32_t pos = wg_base, mine[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (uint32_t kind = 0; kind < 3; kind++)
+#pragma unroll
+                for (uint32_t w = 0; w < BLOCK / 64u; w++) {
+                    if (w == wave) mine[kind] = pos;
+                    pos += wg_count[w][kind];
+                }
+            if (has_e) k_e = mine[0] + prefix_below(m_e);
+            if (has_1) k_1 = mine[1] + prefix_below(m_1);
+            if (has_2) k_2 = mine[2] + prefix_below(m_2);
+        }
+        if (has_e) { a.rq_o[nxt][k_e] = e_o; a.rq_d[nxt][k_e] = e_d; if (e_ans) a.res[nxt][k_e] = make_uint2(__float_as_uint(e_t), (uint32_t)e_p); }
+        if (has_1) { a.rq_o[nxt][k_1] = q1_o; a.rq_d[nxt][k_1] = q1_d; if (q1_ans) a.res[nxt][k_1] = make_uint2(__float_as_uint(q1_t), (uint32_t)q1_p); }
+        if (has_2) { a.rq_o[nxt][k_2] = q2_o; a.rq_d[nxt][k_2] = q2_d; if (q2_ans) a.res[nxt][k_2] = make_uint2(__float_as_uint(q2_t), (uint32_t)q2_p); }
+        // ---- the slot's new state ----
+        if (live_in || regen) {
+            uint32_t nstate = WFQ_DEAD, nflags = 0u, bounce = 0u, draws = 0u;
+            float4 nB = make_float4(1.0f, 1.0f, 0.0f, 0.0f), nC = make_float4(0.0f, 0.0f, __uint_as_float(WFQ_NONE), __uint_as_float(WFQ_NONE));
+            if (got) {
+                nstate = WFQ_RAY;
+                draws = 2u;  // the camera sample has used two values of set 0 (tile.rs:149-153); the ring is refilled from `draws`
+            } else if (hit && !ended_now) {
+                nstate = go_on ? WFQ_RAY : WFQ_FIN;
+                nflags = (df.pending ? WFQ_F_PENDING : 0u) | (df.want1 ? WFQ_F_WANT1 : 0u) | (inf > df.limit1 ? 0u : WFQ_F_LIM1BAD) |
+                         (df.has2 ? WFQ_F_HAS2 : 0u) | (df.spec_tests2 ? WFQ_F_SPEC2 : 0u);
+                bounce = ps.bounce;
+                draws = ps.smp.draws;
+                nB = make_float4(ps.thr.v[0], ps.ppdf.v[0], ps.rad.v[0], df.thr);
+                nC = make_float4(df.c1, df.c2, __uint_as_float(k_1), __uint_as_float(k_2));
+            }
+            a.st_a[slot] = make_uint4(item, bounce | ((nstate | nflags) << 16), draws, k_e);
+            if (nstate != WFQ_DEAD) { a.st_b[slot] = nB; a.st_c[slot] = nC; n_live++; }
+        }
+    }
+    flush_counters(a.counters, cnt);
+    for (int off = 32; off > 0; off >>= 1) n_live += __shfl_down(n_live, off, 64);
+    if (lane_id() == 0u && n_live) atomicAdd(&a.ctr[WFQ_C_LIVE + nxt], n_live);
+}
+
 // ---- the same two stages as separate kernels (profiling / north-star layout) ----
 __global__ void __launch_bounds__(BLOCK) k_pool_init(WfArgs a) {
     const uint32_t slot0 = blockIdx.x * a.slots_per_block;
@@ -1002,12 +1235,27 @@ struct iris_ctx {
     uint32_t *h_live = nullptr;  // pinned
     unsigned long long *h_counters = nullptr;  // pinned: the work counters of a render are copied here
     unsigned char *scratch_ptr = nullptr;  // this device's copy of the static workspace (iris_render_device_noalloc)
+    // queue kernels (k_wfq_*): up to WFQ_MAX_PIPES independent pipelines, each with its own slots, ray queues, counters and stream
+    int64_t wfq_slots = 4 << 20, wfq_pipes = 2, wfq_batch = 8;
+    struct WfqPipe {
+        uint4 *st_a = nullptr;
+        float4 *st_b = nullptr, *st_c = nullptr, *rq_o[2] = {nullptr, nullptr}, *rq_d[2] = {nullptr, nullptr};
+        uint2 *res[2] = {nullptr, nullptr};
+        uint32_t *ctr = nullptr, *stack_hi = nullptr, *h_ctr = nullptr;  // h_ctr: pinned
+        size_t slots_cap = 0, stack_hi_words = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev = nullptr;
+    } wfq[4];
+    hipEvent_t wfq_ev_start = nullptr;
+    bool wfq_now = false;  // this render goes through the queue kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     iris_stats stats = {};
 };
 
 namespace {
 
+constexpr int WFQ_MAX_PIPES = 4;
+void free_wfq(iris_ctx *c);
 constexpr uint32_t SPHERE_CAP = 1024;  // LDS window: 16 KiB of float4 (three pool-kernel workgroups per CU stay resident)
 
 // The host-side hierarchy build lives in iris_bvh_build.cpp (plain C++: it is also compiled, with sanitizers, into the
@@ -1118,6 +1366,133 @@ bool use_register_kernel(const iris_ctx *c) {
     return c->mode == 2 || c->sc.n_prims <= REGISTER_KERNEL_MAX_PRIMS;
 }
 
+// The queue kernels serve scenes with a hierarchy whose BSDFs are Lambertian over constant spectra (one value for the four
+// wavelengths: 48 bytes of path state); mode 0 chooses them there, mode 2 keeps the register-resident kernel.
+bool use_queue_kernels(const iris_ctx *c) {
+    if (c->multi_kernel || c->mode != 3) return false;  // opt-in until it beats the pooled traversal of k_regwave
+    return c->sc.n_bvh_nodes != 0u && c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;
+}
+
+void free_wfq(iris_ctx *c) {
+    for (auto &p : c->wfq) {
+        dev_free(p.st_a); dev_free(p.st_b); dev_free(p.st_c);
+        for (int k = 0; k < 2; k++) { dev_free(p.rq_o[k]); dev_free(p.rq_d[k]); dev_free(p.res[k]); }
+        dev_free(p.ctr); dev_free(p.stack_hi);
+        if (p.h_ctr) (void)hipHostFree(p.h_ctr);
+        if (p.stream) (void)hipStreamDestroy(p.stream);
+        if (p.ev) (void)hipEventDestroy(p.ev);
+        p = iris_ctx::WfqPipe{};
+    }
+    if (c->wfq_ev_start) (void)hipEventDestroy(c->wfq_ev_start);
+    c->wfq_ev_start = nullptr;
+}
+
+int ensure_wfq(iris_ctx *c, int n_pipes, size_t slots, size_t stack_hi_words) {
+    int rc;
+    if (!c->wfq_ev_start) HIP_TRY(c, hipEventCreateWithFlags(&c->wfq_ev_start, hipEventDisableTiming));
+    for (int i = 0; i < n_pipes; i++) {
+        auto &p = c->wfq[i];
+        if (!p.stream) HIP_TRY(c, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        if (!p.ev) HIP_TRY(c, hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+        if (!p.ctr && (rc = dev_alloc(c, &p.ctr, (size_t)WFQ_C_WORDS))) return rc;
+        if (!p.h_ctr) HIP_TRY(c, hipHostMalloc((void **)&p.h_ctr, WFQ_C_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        if (p.slots_cap < slots) {
+            dev_free(p.st_a); dev_free(p.st_b); dev_free(p.st_c);
+            p.st_a = nullptr; p.st_b = p.st_c = nullptr;
+            for (int k = 0; k < 2; k++) { dev_free(p.rq_o[k]); dev_free(p.rq_d[k]); dev_free(p.res[k]); p.rq_o[k] = p.rq_d[k] = nullptr; p.res[k] = nullptr; }
+            p.slots_cap = 0;
+            if ((rc = dev_alloc(c, &p.st_a, slots)) || (rc = dev_alloc(c, &p.st_b, slots)) || (rc = dev_alloc(c, &p.st_c, slots))) return rc;
+            for (int k = 0; k < 2; k++)  // a slot sends at most three rays per pass
+                if ((rc = dev_alloc(c, &p.rq_o[k], 3 * slots)) || (rc = dev_alloc(c, &p.rq_d[k], 3 * slots)) || (rc = dev_alloc(c, &p.res[k], 3 * slots))) return rc;
+            p.slots_cap = slots;
+        }
+        if (p.stack_hi_words < stack_hi_words) {
+            dev_free(p.stack_hi);
+            p.stack_hi = nullptr;
+            p.stack_hi_words = 0;
+            if ((rc = dev_alloc(c, &p.stack_hi, stack_hi_words))) return rc;
+            p.stack_hi_words = stack_hi_words;
+        }
+    }
+    return IRIS_OK;
+}
+
+// One chunk of a render through the queue kernels.  `a`: the chunk as launch_chunk gets it (scene, camera, items, result buffer).
+template <int INTEG>
+int run_wfq(iris_ctx *c, const WfArgs &a, hipStream_t stream) {
+    const uint32_t tiles_needed = (a.n_items + BLOCK - 1u) / BLOCK;
+    int n_pipes = (int)std::min<int64_t>(c->wfq_pipes, WFQ_MAX_PIPES);
+    while (n_pipes > 1 && tiles_needed < (uint32_t)n_pipes * 64u) n_pipes--;  // small renders: one pipeline
+    const size_t cap = std::max<size_t>(BLOCK, ((size_t)c->wfq_slots / n_pipes) & ~(size_t)(BLOCK - 1));
+    const size_t slots = std::min<size_t>(cap, (size_t)((tiles_needed + n_pipes - 1) / n_pipes) * BLOCK);
+    const uint32_t trace_blocks = (uint32_t)c->n_cus * 8u, lds_n = std::min<uint32_t>(std::max<uint32_t>(c->bvh_depth, 1u), WFQ_STACK_LDS);
+    const uint32_t shade_blocks = std::min<uint32_t>((uint32_t)(slots / BLOCK), (uint32_t)c->n_cus * 6u);
+    const size_t stack_hi_words = c->bvh_depth > lds_n ? (size_t)trace_blocks * BLOCK * (c->bvh_depth - lds_n) : 1;
+    int rc;
+    if ((rc = ensure_wfq(c, n_pipes, slots, stack_hi_words))) return rc;
+    WfqArgs q[WFQ_MAX_PIPES];
+    HIP_TRY(c, hipEventRecord(c->wfq_ev_start, stream));
+    for (int i = 0; i < n_pipes; i++) {
+        auto &p = c->wfq[i];
+        WfqArgs &w = q[i];
+        w.sc = a.sc; w.cam = a.cam; w.fr = a.fr;
+        w.st_a = p.st_a; w.st_b = p.st_b; w.st_c = p.st_c;
+        for (int k = 0; k < 2; k++) { w.rq_o[k] = p.rq_o[k]; w.rq_d[k] = p.rq_d[k]; w.res[k] = p.res[k]; }
+        w.ctr = p.ctr;
+        w.results = a.results;
+        w.counters = a.counters;
+        w.work_cursor = a.work_cursor;
+        w.npix = a.npix; w.div_npix = a.div_npix; w.div_width = a.div_width;
+        w.s_begin = a.s_begin; w.n_items = a.n_items; w.n_slots = (uint32_t)slots;
+        w.par = 0u; w.seed_pass = 1u;
+        w.stack_hi = p.stack_hi;
+        w.stack_lds_n = lds_n;
+        HIP_TRY(c, hipStreamWaitEvent(p.stream, c->wfq_ev_start, 0));
+        HIP_TRY(c, hipMemsetAsync(p.ctr, 0, WFQ_C_WORDS * sizeof(uint32_t), p.stream));
+    }
+    uint32_t pass[WFQ_MAX_PIPES] = {0u, 0u, 0u, 0u};
+    bool active[WFQ_MAX_PIPES] = {false, false, false, false};
+    auto enqueue = [&](int i) -> int {  // one batch of passes on pipeline i, then its counters to the host
+        auto &p = c->wfq[i];
+        WfqArgs &w = q[i];
+        for (int64_t b = 0; b < c->wfq_batch; b++) {
+            w.par = pass[i] & 1u;
+            w.seed_pass = pass[i] == 0u ? 1u : 0u;
+            if (pass[i] != 0u) {
+                hipLaunchKernelGGL(k_wfq_trace, dim3(trace_blocks), dim3(BLOCK), (size_t)lds_n * BLOCK * sizeof(uint32_t), p.stream, w);
+                c->stats.launches += 1;
+            }
+            hipLaunchKernelGGL(k_wfq_shade<INTEG>, dim3(shade_blocks), dim3(BLOCK), 0, p.stream, w);
+            c->stats.launches += 1;
+            pass[i]++;
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(p.h_ctr, p.ctr, WFQ_C_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, p.stream));
+        return IRIS_OK;
+    };
+    for (int i = 0; i < n_pipes; i++) {
+        active[i] = true;
+        if ((rc = enqueue(i))) return rc;
+    }
+    for (int left = n_pipes; left > 0;) {
+        for (int i = 0; i < n_pipes; i++) {
+            if (!active[i]) continue;
+            HIP_TRY(c, hipStreamSynchronize(c->wfq[i].stream));
+            if (c->wfq[i].h_ctr[WFQ_C_LIVE + (pass[i] & 1u)] == 0u) {  // no path left in this pipeline (and the item counter is past the end)
+                active[i] = false;
+                left--;
+            } else if ((rc = enqueue(i))) {
+                return rc;
+            }
+        }
+    }
+    for (int i = 0; i < n_pipes; i++) {
+        HIP_TRY(c, hipEventRecord(c->wfq[i].ev, c->wfq[i].stream));
+        HIP_TRY(c, hipStreamWaitEvent(stream, c->wfq[i].ev, 0));
+    }
+    return IRIS_OK;
+}
+
 // Workgroups of the fused pool/queue kernel that one CU holds at a time (registers, LDS).
 template <int INTEG>
 int pool_blocks_per_cu(const iris_ctx *c, size_t dyn_lds) {
@@ -1134,6 +1509,7 @@ template <int INTEG>
 int launch_chunk(iris_ctx *c, const WfArgs &a, uint32_t blocks, hipStream_t stream) {
     size_t dyn = (size_t)a.sphere_cap * sizeof(float4);
     const bool lc = c->scene_class == IRIS_CLS_LAMBERT_CONSTANT, env = c->scene_class == IRIS_CLS_GENERAL_ENV;
+    if (c->wfq_now) return run_wfq<INTEG>(c, a, stream);
     if (use_register_kernel(c)) {
         const bool bvh = c->sc.n_bvh_nodes != 0u;
 #define IRIS_LAUNCH_REG(CLS_)                                                                                                   \
@@ -1199,6 +1575,9 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     c->stats = iris_stats{};
     const bool reg = use_register_kernel(c);
     if (no_alloc && !reg) return fail(c, IRIS_E_LIMIT, "iris_render_device_noalloc serves the scenes of the register-resident kernel only (up to 64 spheres, or a hierarchy)");
+    const bool wfq = !no_alloc && use_queue_kernels(c);  // the queue kernels keep gigabytes of queues and synchronise with the host: not for the no-alloc entry
+    if (c->mode == 3 && !wfq) return fail(c, IRIS_E_ARG, "mode 3 (queue kernels) needs a scene with a hierarchy whose BSDFs are all Lambertian over constant spectra");
+    c->wfq_now = wfq;
     int64_t per_cu = reg ? c->reg_blocks_per_cu : c->blocks_per_cu;
     if (no_alloc) per_cu = std::min<int64_t>(per_cu, 4);  // a CU holds at most 4 of these workgroups; a smaller grid keeps the per-wave queues small
     const bool pooled = reg && c->sc.n_bvh_nodes && c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;  // k_regwave<.., LAMBERT_CONSTANT, true>: the ray pool
@@ -1221,9 +1600,9 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     const uint32_t reg_stack_lds = std::min<uint32_t>(std::max<uint32_t>(c->bvh_depth, 1u), REG_STACK_LDS);
     // sky mask: register kernel on a short list without an environment map
     const bool use_sky = c->sky_mask && reg && !c->sc.n_bvh_nodes && c->sc.env_w == 0u && p->spp_count != 0u && p->max_depth != 0u;
-    const size_t stack_hi_words = (reg && c->sc.n_bvh_nodes && c->bvh_depth > reg_stack_lds) ? (size_t)blocks * BLOCK * (c->bvh_depth - reg_stack_lds) : 0;
+    const size_t stack_hi_words = (reg && !wfq && c->sc.n_bvh_nodes && c->bvh_depth > reg_stack_lds) ? (size_t)blocks * BLOCK * (c->bvh_depth - reg_stack_lds) : 0;
     const size_t xq_waves = (reg && c->scene_class == IRIS_CLS_GENERAL) ? (size_t)blocks * (BLOCK / 64) : 0;
-    const size_t park_words = pooled ? (size_t)blocks * BLOCK * IRIS_WALK_WORDS : 0;
+    const size_t park_words = (pooled && !wfq) ? (size_t)blocks * BLOCK * IRIS_WALK_WORDS : 0;
     uint32_t spp_per_chunk;
     Workspace ws;
     if (no_alloc) {
@@ -1354,7 +1733,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         // still gets several
         const uint32_t run_cap = c->sc.n_bvh_nodes ? 256u : (c->scene_class == IRIS_CLS_LAMBERT_CONSTANT ? 2048u : 512u);
         a.work_run = c->work_run ? (uint32_t)c->work_run : std::min<uint32_t>(run_cap, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
-        if (reg) HIP_TRY(c, hipMemsetAsync(ws.work_cursor, 0, sizeof(unsigned long long), stream));
+        if (reg || wfq) HIP_TRY(c, hipMemsetAsync(ws.work_cursor, 0, sizeof(unsigned long long), stream));
         a.x_park_max = (uint32_t)c->x_park_max;
         a.x_fire = (uint32_t)c->x_fire;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
@@ -1415,7 +1794,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     c->stats.resolve_ms = resolve_ms;
     c->stats.bvh_depth = c->bvh_depth;
     c->stats.sky_samples = h[10];
-    c->stats.kernel = reg ? IRIS_KERNEL_REGISTER : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED);
+    c->stats.kernel = wfq ? IRIS_KERNEL_QUEUES : (reg ? IRIS_KERNEL_REGISTER : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED));
     return IRIS_OK;
 }
 
@@ -1451,6 +1830,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_pools(c);
+    free_wfq(c);
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind); dev_free(c->d_light_rec);
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
@@ -1481,7 +1861,7 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "multi_kernel") {
         c->multi_kernel = value ? 1 : 0;
     } else if (k == "mode") {
-        if (value < 0 || value > 2) return fail(c, IRIS_E_ARG, "mode must be 0 (auto), 1 (pool) or 2 (register)");
+        if (value < 0 || value > 3) return fail(c, IRIS_E_ARG, "mode must be 0 (auto), 1 (pool), 2 (register) or 3 (queues)");
         c->mode = value;
     } else if (k == "bvh_min_prims") {
         if (value < 0) return fail(c, IRIS_E_ARG, "bvh_min_prims must be >= 0");
@@ -1505,6 +1885,15 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "work_run") {
         if (value < 0 || value > (1 << 20) || value % 64) return fail(c, IRIS_E_ARG, "work_run must be 0 (auto) or a multiple of 64 up to 2^20");
         c->work_run = value;
+    } else if (k == "wfq_slots") {
+        if (value < BLOCK || value > (1ll << 28) || value % BLOCK) return fail(c, IRIS_E_ARG, "wfq_slots must be a multiple of 256 in [256, 2^28]");
+        c->wfq_slots = value;
+    } else if (k == "wfq_pipes") {
+        if (value < 1 || value > WFQ_MAX_PIPES) return fail(c, IRIS_E_ARG, "wfq_pipes out of range [1, 4]");
+        c->wfq_pipes = value;
+    } else if (k == "wfq_batch") {
+        if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "wfq_batch out of range [1, 1024]");
+        c->wfq_batch = value;
     } else if (k == "reg_blocks_per_cu") {
         if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "reg_blocks_per_cu out of range [1, 1024]");
         c->reg_blocks_per_cu = value;

@@ -73,7 +73,7 @@ class Stats(C.Structure):
                 ("kernel", C.c_uint32), ("bvh_depth", C.c_uint32), ("sky_samples", C.c_uint64)]
 
 
-KERNEL_NAMES = ("k_wavefront", "k_stage_gen_extend+k_stage_shade", "k_regwave")
+KERNEL_NAMES = ("k_wavefront", "k_stage_gen_extend+k_stage_shade", "k_regwave", "k_wfq_shade+k_wfq_trace")
 
 
 class Trace(C.Structure):
