@@ -147,6 +147,40 @@ bool build_bvh(const iris_sphere *sp, uint32_t n, uint32_t leaf, Bvh &out) {
         if (out.depth <= IRIS_BVH_STACK) { order = work; break; }
         if (attempt == 1) return false;
     }
+    // the 16-bit grid records (iris_bvh_build.h): grid over the root box, four units of margin below, the scale a little over
+    // extent / 65528 so that every upper bound stays below 65535 after its outward rounding and the extra unit
+    {
+        const Float4 rlo = out.nodes[0], rhi = out.nodes[1];
+        const double ext = std::max({(double)rhi.x - rlo.x, (double)rhi.y - rlo.y, (double)rhi.z - rlo.z, 1e-30});
+        const float s = (float)(ext * (1.0 + 1e-6) / 65528.0);
+        if (!(s > 0.0f) || !std::isfinite(s)) return false;
+        out.grid_scale = s;
+        out.grid_inv_scale = (float)(1.0 / (double)s);
+        const float root_lo[3] = {rlo.x, rlo.y, rlo.z};
+        for (int k = 0; k < 3; k++) out.grid_origin[k] = std::nextafter((float)((double)root_lo[k] - 4.0 * (double)s), -INFINITY);
+        const size_t n_nodes = out.nodes.size() / 2;
+        out.qnodes.assign(4 * (n_nodes - 1), 0u);
+        for (size_t k = 1; k < n_nodes; k++) {
+            const Float4 lo = out.nodes[2 * k], hi = out.nodes[2 * k + 1];
+            const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+            uint32_t ql[3], qh[3];
+            for (int a = 0; a < 3; a++) {
+                const double g = (double)out.grid_origin[a];
+                const double fl = std::floor(((double)l[a] - g) / (double)s) - 1.0, ch = std::ceil(((double)h[a] - g) / (double)s) + 1.0;
+                if (!(fl >= 0.0) || !(ch <= 65535.0)) return false;  // cannot happen by the choice of origin and scale
+                ql[a] = (uint32_t)fl;
+                qh[a] = (uint32_t)ch;
+            }
+            uint32_t first, count;
+            std::memcpy(&first, &lo.w, 4);
+            std::memcpy(&count, &hi.w, 4);
+            uint32_t *q = &out.qnodes[4 * (k - 1)];
+            q[0] = ql[0] | (ql[1] << 16);
+            q[1] = ql[2] | (qh[0] << 16);
+            q[2] = qh[1] | (qh[2] << 16);
+            q[3] = first | (count << 29);
+        }
+    }
     // leaf-ordered arrays: the tree's spheres first (node `first` fields index them), the big ones behind them
     out.n_big = (uint32_t)big.size();
     out.prim = order;

@@ -19,6 +19,13 @@ struct Bvh {
     std::vector<Float4> nodes;    // two per node: (lo, first), (hi, count); count > 0: leaf over leaf-ordered spheres [first, first + count)
     std::vector<Float4> spheres;  // (cx, cy, cz, r * r) in leaf order
     std::vector<uint32_t> prim;   // primitive index of each leaf-ordered sphere
+    // The nodes as the traversal reads them: one 16-byte record per node except the root, record k - 1 for node k, so that the two
+    // children of a node (k, k + 1 with k odd) are one 32-byte-aligned pair: {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16,
+    // first | count << 29}, box coordinates on a 16-bit grid over the root box (grid_origin + q * grid_scale, the same scale on the
+    // three axes), rounded outwards and grown by one more unit, so that the quantised box contains the node's box whatever the
+    // rounding of the device's grid arithmetic (box_entry_q, iris_device.h).
+    std::vector<uint32_t> qnodes;
+    float grid_origin[3] = {0.0f, 0.0f, 0.0f}, grid_scale = 1.0f, grid_inv_scale = 1.0f;
     uint32_t depth = 0;
     uint32_t n_big = 0;  // the last n_big leaf-ordered spheres are outside the tree
     uint32_t leaf = 4;   // spheres per leaf, <= 7: a node reference keeps the count in three bits, the first sphere in 29 (option bvh_leaf)

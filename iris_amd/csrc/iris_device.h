@@ -623,6 +623,11 @@ struct SceneDev {
     // float4: (lo.xyz, first) and (hi.xyz, count); count > 0: leaf holding leaf-ordered spheres
     // [first, first + count); count == 0: inner node whose children are nodes first and first + 1.
     const float4 *bvh_nodes;
+    // The same nodes as the traversal reads them (iris_bvh_build.h): 16 bytes per node, boxes on a 16-bit grid, both children of
+    // a node in one aligned 32-byte pair -- half the bytes, and so half the vector-L1 requests, of the float records, which is
+    // what bounds the traversal.  bvh_nodes keeps the float boxes; the root's is tested from there.
+    const uint4 *bvh_q;
+    float bvh_g0[3], bvh_s, bvh_inv_s;
     const float4 *bvh_spheres;   // (cx, cy, cz, r * r) in leaf order
     const uint32_t *bvh_prim;    // primitive index of each leaf-ordered sphere
     uint32_t n_bvh_nodes;
@@ -787,8 +792,7 @@ IRIS_DEV void scan_window(const float4 *win, uint32_t n, uint32_t base, const Ra
 // test has at hand): a sub-pixel sphere far away is "fat" for the reference's arithmetic, and is for the traversal too, while
 // boxes near the origin stay tight.  (The host adds 16 ulps of the coordinates for the rounding of the slab arithmetic itself.)
 #define IRIS_BVH_PAD 1.2e-3f
-IRIS_DEV float box_entry(float4 lo, float4 hi, V3 o, V3 inv, float closest_t) {
-    const float dx0 = lo.x - o.x, dx1 = hi.x - o.x, dy0 = lo.y - o.y, dy1 = hi.y - o.y, dz0 = lo.z - o.z, dz1 = hi.z - o.z;
+IRIS_DEV float box_entry_d(float dx0, float dx1, float dy0, float dy1, float dz0, float dz1, V3 inv, float closest_t) {
     const float pad = IRIS_BVH_PAD * ((__builtin_fmaxf(fabs_(dx0), fabs_(dx1)) + __builtin_fmaxf(fabs_(dy0), fabs_(dy1))) + __builtin_fmaxf(fabs_(dz0), fabs_(dz1)));
     float tx0 = (dx0 - pad) * inv.x, tx1 = (dx1 + pad) * inv.x;
     float ty0 = (dy0 - pad) * inv.y, ty1 = (dy1 + pad) * inv.y;
@@ -797,6 +801,27 @@ IRIS_DEV float box_entry(float4 lo, float4 hi, V3 o, V3 inv, float closest_t) {
     float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx0, tx1), __builtin_fminf(ty0, ty1)), __builtin_fmaxf(__builtin_fminf(tz0, tz1), 0.0f));
     float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx0, tx1), __builtin_fmaxf(ty0, ty1)), __builtin_fmaxf(tz0, tz1));
     return (tmin <= tmax && tmin <= closest_t) ? tmin : __builtin_inff();  // inf: do not enter
+}
+IRIS_DEV float box_entry(float4 lo, float4 hi, V3 o, V3 inv, float closest_t) {
+    return box_entry_d(lo.x - o.x, hi.x - o.x, lo.y - o.y, hi.y - o.y, lo.z - o.z, hi.z - o.z, inv, closest_t);
+}
+// The same test on a 16-bit grid record, in grid coordinates: the ray's origin is moved to the grid once per ray (og = (o - grid
+// origin) / scale, inv_g = scale / d), the record's six integers convert exactly (one v_cvt_f32_u32 with a 16-bit source select
+// each), and the distances come out in the ray's own parameter.  What the grid arithmetic can lose: og carries a relative error of
+// 3 x 2^-24 (a subtraction, the rounded reciprocal of the scale, a product), i.e. at most 0.012 units for an origin inside the grid
+// and 1.8e-7 |og| outside; the record is rounded outwards by up to a unit and then grown by one more (the host), which covers the
+// first, and the per-ray, per-box pad of 1.2e-3 x distance, derived with 1.05e-3 needed, covers the second a hundred times over.
+struct BvhRay { V3 og, inv_g; };
+IRIS_DEV BvhRay bvh_ray(const SceneDev &sc, V3 o, V3 inv) {
+    BvhRay r;
+    r.og = v3((o.x - sc.bvh_g0[0]) * sc.bvh_inv_s, (o.y - sc.bvh_g0[1]) * sc.bvh_inv_s, (o.z - sc.bvh_g0[2]) * sc.bvh_inv_s);
+    r.inv_g = v3(inv.x * sc.bvh_s, inv.y * sc.bvh_s, inv.z * sc.bvh_s);
+    return r;
+}
+IRIS_DEV float box_entry_q(uint4 c, const BvhRay &r, float closest_t) {
+    const float lx = (float)(c.x & 0xffffu), ly = (float)(c.x >> 16), lz = (float)(c.y & 0xffffu);
+    const float hx = (float)(c.y >> 16), hy = (float)(c.z & 0xffffu), hz = (float)(c.z >> 16);
+    return box_entry_d(lx - r.og.x, hx - r.og.x, ly - r.og.y, hy - r.og.y, lz - r.og.z, hz - r.og.z, r.inv_g, closest_t);
 }
 // one leaf-ordered sphere, with the tie rule on the primitive index (visiting order is not index order)
 IRIS_DEV void bvh_sphere_test(const SceneDev &sc, uint32_t slot, const Ray &ray, float a, exact::Recip ya, float &closest_t, int &closest) {
@@ -841,6 +866,7 @@ IRIS_DEV V3 bvh_inv_dir(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_
 template <bool ANY>
 IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &ray, float a, float &closest_t, int &closest, unsigned long long &tests, int tie = 0x7fffffff) {
     const V3 inv = bvh_inv_dir(ray.d);
+    const BvhRay br = bvh_ray(sc, ray.o, inv);
     const exact::Recip ya = exact::recip_for(a);
     uint32_t n_tests = sc.bvh_big_count;
     for (uint32_t k = 0; k < sc.bvh_big_count; k++) {
@@ -858,13 +884,12 @@ IRIS_DEV void bvh_closest(const SceneDev &sc, const SphereStage &st, const Ray &
     for (;;) {
         while (have && (ref >> 29) == 0u) {
             const uint32_t first = ref & 0x1fffffffu;
-            const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
-            const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];
-            const float tl = box_entry(l0, l1, ray.o, inv, closest_t), tr = box_entry(r0, r1, ray.o, inv, closest_t);
+            const uint4 cl = sc.bvh_q[first - 1u], cr = sc.bvh_q[first];
+            const float tl = box_entry_q(cl, br, closest_t), tr = box_entry_q(cr, br, closest_t);
             const bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
             if (hl || hr) {
                 const bool left_first = hl && (!hr || tl <= tr);
-                const uint32_t ref_l = bvh_ref(l0, l1), ref_r = bvh_ref(r0, r1);
+                const uint32_t ref_l = cl.w, ref_r = cr.w;
                 if (hl && hr) {  // the farther child waits on the stack (depth <= IRIS_BVH_STACK by construction)
                     bvh_push(st, sp, left_first ? ref_r : ref_l);
                     sp++;
@@ -1000,7 +1025,8 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
 #endif
     bool have = false, any = false;
     uint32_t my = 0u, ref = 0u, sp = 0u, n_tests = 0u;
-    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f), inv = v3(0.0f, 0.0f, 0.0f);
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
+    BvhRay br = {v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 0.0f)};
     float a = 1.0f, cull_t = 0.0f;
     exact::Recip ya = {1.0f};
     int closest = -1;
@@ -1016,7 +1042,7 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
         for (uint32_t k = 0; k < sp; k++) bvh_push(st, k, park[(10u + k) * park_stride]);
         a = len_squared(d);
         ya = exact::recip_for(a);
-        inv = bvh_inv_dir(d);
+        br = bvh_ray(sc, o, bvh_inv_dir(d));
         have = true;
         walking = false;
     }
@@ -1038,7 +1064,8 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
                 closest = __float_as_int(rec[7u * IRIS_POOL_CAP + k]) + IRIS_POOL_OUT;
                 a = len_squared(d);  // sphere.rs:27
                 ya = exact::recip_for(a);
-                inv = bvh_inv_dir(d);
+                const V3 inv = bvh_inv_dir(d);
+                br = bvh_ray(sc, o, inv);
                 const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
                 ref = bvh_ref(root_lo, root_hi);
                 sp = 0u;
@@ -1065,13 +1092,12 @@ IRIS_DEV void bvh_pool_pass(const SceneDev &sc, const SphereStage &st, float *re
             for (int rep = 0; rep < IRIS_POOL_INNER_REPS; rep++)
             if (have && (ref >> 29) == 0u) {
                 const uint32_t first = ref & 0x1fffffffu;
-                const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
-                const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];
-                const float tl = box_entry(l0, l1, o, inv, cull_t), tr = box_entry(r0, r1, o, inv, cull_t);
+                const uint4 cl = sc.bvh_q[first - 1u], cr = sc.bvh_q[first];
+                const float tl = box_entry_q(cl, br, cull_t), tr = box_entry_q(cr, br, cull_t);
                 const bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
                 if (hl || hr) {
                     const bool left_first = hl && (!hr || tl <= tr);
-                    const uint32_t ref_l = bvh_ref(l0, l1), ref_r = bvh_ref(r0, r1);
+                    const uint32_t ref_l = cl.w, ref_r = cr.w;
                     if (hl && hr) {
                         bvh_push(st, sp, left_first ? ref_r : ref_l);
                         sp++;
@@ -1176,31 +1202,48 @@ IRIS_DEV void wfq_prepare(const SceneDev &sc, const Ray &ray, bool any, float li
     const uint32_t word = answered ? IRIS_WFQ_DONE : (any ? (IRIS_WFQ_ANY | ((uint32_t)tie & 0x7fffffffu)) : (uint32_t)(closest + 1));
     rec_d = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(word));
 }
-// One wave's share of a queue of n_rays rays: chunks of `claim` consecutive rays from `cursor`, handed to the lanes as they fall idle.
+// One wave's share of the ray queue.  The queue is cut into REGIONS of IRIS_WFQ_REGION positions, one per tile of 256 path slots
+// (a slot sends at most three rays per pass), filled from their start: region r holds n_region[r] rays (so the producer needs no
+// atomic to append).  A wave claims one region at a time from `cursor` and hands its rays to its lanes as they fall idle.
+// (Tried and dropped: two lanes per ray, each fetching and testing one child and swapping results through DPP -- bit-exact, but
+// 124 ms against 109 ms for the trace kernels of config D: the vector L1 serves about one 16-byte lane request per cycle whichever
+// lane asks, so the requests per ray, not the lanes, are what has to shrink -- see the compressed nodes, box_entry_q.)
+#define IRIS_WFQ_REGION 768u
+#ifdef IRIS_WFQ_STATS  // diagnostic build: rounds and the lanes busy in them -- fetches, rays fetched, inner rounds, lanes at each inner step, leaf rounds, lanes, all rounds, lanes holding a ray
+__device__ unsigned long long g_wfq_stats[8];
+#define IRIS_WFQ_STAT(k, v) do { ws_[k] += (v); } while (0)
+#else
+#define IRIS_WFQ_STAT(k, v) do { } while (0)
+#endif
 IRIS_DEV void wfq_trace_wave(const SceneDev &sc, const SphereStage &st, const float4 *__restrict__ rq_o, const float4 *__restrict__ rq_d, uint2 *__restrict__ res,
-                             uint32_t n_rays, uint32_t *cursor, uint32_t claim, unsigned long long &tests) {
+                             const uint32_t *__restrict__ n_region, uint32_t n_regions, uint32_t *cursor, unsigned long long &tests) {
     bool have = false, any = false, more = true;
     uint32_t my = 0u, ref = 0u, sp = 0u, n_tests = 0u, w_next = 0u, w_lim = 0u;
-    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f), inv = v3(0.0f, 0.0f, 0.0f);
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, 1.0f);
+    BvhRay br = {v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 0.0f)};
     float a = 1.0f, cull_t = 0.0f;
     exact::Recip ya = {1.0f};
     int closest = -1, tie = 0;
     const float4 root_lo = sc.bvh_nodes[0], root_hi = sc.bvh_nodes[1];
     const uint32_t root_ref = bvh_ref(root_lo, root_hi);
+#ifdef IRIS_WFQ_STATS
+    unsigned long long ws_[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
     for (;;) {
         unsigned long long m_have = __ballot(have);
         uint32_t n_have = (uint32_t)__popcll(m_have);
         // ---- fetch: lanes without a ray take the next rays of the wave's chunk (a new chunk when that one is used up) ----
         if (more && (n_have == 0u || 64u - n_have >= IRIS_WFQ_FETCH_MIN)) {
             if (w_next >= w_lim) {
-                uint32_t start = 0u;
-                if (lanes_below(~0ull) == 0u) start = atomicAdd(cursor, claim);
-                start = __builtin_amdgcn_readfirstlane(start);
-                if (start >= n_rays) more = false;
-                else { w_next = start; w_lim = min(start + claim, n_rays); }
+                uint32_t r = 0u;
+                if (lanes_below(~0ull) == 0u) r = atomicAdd(cursor, 1u);
+                r = __builtin_amdgcn_readfirstlane(r);
+                if (r >= n_regions) more = false;
+                else { w_next = r * IRIS_WFQ_REGION; w_lim = w_next + n_region[r]; }
             }
-            if (more) {
+            if (more && w_next < w_lim) {
                 const uint32_t n_take = min(64u - n_have, w_lim - w_next), r = lanes_below(~m_have);
+                IRIS_WFQ_STAT(0, 1ull); IRIS_WFQ_STAT(1, (unsigned long long)n_take);
                 if (!have && r < n_take) {
                     my = w_next + r;
                     const float4 ro = rq_o[my], rd = rq_d[my];
@@ -1214,7 +1257,7 @@ IRIS_DEV void wfq_trace_wave(const SceneDev &sc, const SphereStage &st, const fl
                         closest = any ? -1 : (int)word - 1;
                         a = len_squared(d);  // sphere.rs:27
                         ya = exact::recip_for(a);
-                        inv = bvh_inv_dir(d);
+                        br = bvh_ray(sc, o, bvh_inv_dir(d));
                         ref = root_ref;
                         sp = 0u;
                         have = true;
@@ -1232,18 +1275,20 @@ IRIS_DEV void wfq_trace_wave(const SceneDev &sc, const SphereStage &st, const fl
         // ---- one kind of step per round, the kind more lanes are waiting for: inner nodes or leaves ----
         const bool at_inner = have && (ref >> 29) == 0u;
         const uint32_t n_inner = (uint32_t)__popcll(__ballot(at_inner));
+        IRIS_WFQ_STAT(6, 1ull); IRIS_WFQ_STAT(7, (unsigned long long)n_have);
         if (100u * n_inner >= IRIS_WFQ_INNER_PCT * n_have) {
+            IRIS_WFQ_STAT(2, 1ull);
 #pragma unroll
             for (int rep = 0; rep < IRIS_WFQ_INNER_REPS; rep++)
             if (have && (ref >> 29) == 0u) {
+                IRIS_WFQ_STAT(3, (unsigned long long)__popcll(__ballot(true)));
                 const uint32_t first = ref & 0x1fffffffu;
-                const float4 l0 = sc.bvh_nodes[2u * first], l1 = sc.bvh_nodes[2u * first + 1u];
-                const float4 r0 = sc.bvh_nodes[2u * first + 2u], r1 = sc.bvh_nodes[2u * first + 3u];
-                const float tl = box_entry(l0, l1, o, inv, cull_t), tr = box_entry(r0, r1, o, inv, cull_t);
+                const uint4 cl = sc.bvh_q[first - 1u], cr = sc.bvh_q[first];
+                const float tl = box_entry_q(cl, br, cull_t), tr = box_entry_q(cr, br, cull_t);
                 const bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
                 if (hl || hr) {
                     const bool left_first = hl && (!hr || tl <= tr);
-                    const uint32_t ref_l = bvh_ref(l0, l1), ref_r = bvh_ref(r0, r1);
+                    const uint32_t ref_l = cl.w, ref_r = cr.w;
                     if (hl && hr) {
                         bvh_push(st, sp, left_first ? ref_r : ref_l);
                         sp++;
@@ -1257,6 +1302,7 @@ IRIS_DEV void wfq_trace_wave(const SceneDev &sc, const SphereStage &st, const fl
                 }
             }
         } else if (have && !at_inner) {
+            IRIS_WFQ_STAT(4, 1ull); IRIS_WFQ_STAT(5, (unsigned long long)__popcll(__ballot(true)));
             const uint32_t first = ref & 0x1fffffffu, count = ref >> 29;
             for (uint32_t j = 0; j < count; j++) wfq_sphere_test(sc, first + j, o, d, a, ya, any, tie, cull_t, closest);
             n_tests += count;
@@ -1273,6 +1319,10 @@ IRIS_DEV void wfq_trace_wave(const SceneDev &sc, const SphereStage &st, const fl
             res[my] = make_uint2(__float_as_uint(cull_t), (uint32_t)closest);
     }
     tests += n_tests;
+#ifdef IRIS_WFQ_STATS
+    if (lanes_below(~0ull) == 0u)
+        for (int k = 0; k < 8; k++) atomicAdd(&g_wfq_stats[k], ws_[k]);
+#endif
 }
 
 // Scene::intersection / ray_hits_point / ray_hits_object all reduce to this scan (scene.rs:116-166):

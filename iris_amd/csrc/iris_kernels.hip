@@ -713,6 +713,7 @@ constexpr uint32_t WFQ_DEAD = 0u, WFQ_RAY = 1u, WFQ_FIN = 2u;  // slot state (bi
 constexpr uint32_t WFQ_F_PENDING = 4u, WFQ_F_WANT1 = 8u, WFQ_F_LIM1BAD = 16u, WFQ_F_HAS2 = 32u, WFQ_F_SPEC2 = 64u;
 constexpr uint32_t WFQ_NONE = 0xffffffffu;
 enum : uint32_t { WFQ_C_NRAYS = 0u, WFQ_C_CURSOR = 2u, WFQ_C_LIVE = 4u, WFQ_C_WORDS = 8u };
+static_assert(IRIS_WFQ_REGION == 3u * BLOCK, "a region of the ray queue holds the rays of one tile of slots: at most three per slot");
 constexpr uint32_t WFQ_STACK_LDS = 8u;  // traversal-stack entries per lane kept in LDS by k_wfq_trace (8 KiB per workgroup)
 
 struct WfqArgs {
@@ -724,17 +725,22 @@ struct WfqArgs {
     float4 *st_c;   // deferred contributions c1, c2; queue positions of the two visibility queries (bits; WFQ_NONE: none)
     float4 *rq_o[2], *rq_d[2];  // ray queues: (o, cull_t), (d, word) -- wfq_prepare
     uint2 *res[2];              // per queue position: (t bits, primitive or -1)
-    uint32_t *ctr;              // WFQ_C_*: rays queued [2], trace cursor [2], live paths [2]
+    uint32_t *n_region[2];      // rays in each region of IRIS_WFQ_REGION queue positions (region r = the rays of slots 256 r .. 256 r + 255)
+    uint2 *wg_run;              // per k_wfq_shade workgroup: the unclaimed rest [next, end) of its current run of items, kept between passes
+    uint32_t *ctr;              // WFQ_C_*: trace cursor [2], live paths [2]
     XyzResult *results;
     unsigned long long *counters, *work_cursor;
     uint32_t npix;
     FastDiv div_npix, div_width;
-    uint32_t s_begin, n_items, n_slots, par, seed_pass;
+    uint32_t s_begin, n_items, n_slots, par, seed_pass, item_run;
     uint32_t *stack_hi;
     uint32_t stack_lds_n;
 };
 
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8))) k_wfq_trace(WfqArgs a) {
+#ifndef IRIS_WFQ_TRACE_WAVES
+#define IRIS_WFQ_TRACE_WAVES 8
+#endif
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRIS_WFQ_TRACE_WAVES))) k_wfq_trace(WfqArgs a) {
     extern __shared__ float4 stack_win[];
     SphereStage st;
     st.lds = stack_win;
@@ -746,16 +752,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
     st.stack_hi = a.stack_hi + (size_t)blockIdx.x * BLOCK + threadIdx.x;
     st.stack_hi_stride = gridDim.x * BLOCK;
     const uint32_t par = a.par;
-    if (blockIdx.x == 0u && threadIdx.x == 0u) {  // what the next k_wfq_shade appends to, and the cursor of the next k_wfq_trace
-        a.ctr[WFQ_C_NRAYS + (par ^ 1u)] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {  // the cursor of the next k_wfq_trace, and what the next k_wfq_shade adds to
         a.ctr[WFQ_C_CURSOR + (par ^ 1u)] = 0u;
         a.ctr[WFQ_C_LIVE + (par ^ 1u)] = 0u;
     }
-    const uint32_t n_rays = a.ctr[WFQ_C_NRAYS + par];
-    const uint32_t n_waves = gridDim.x * (BLOCK / 64u);
-    const uint32_t claim = min(512u, max(64u, (n_rays / n_waves) & ~63u));  // small queues are spread over the whole chip
     unsigned long long tests = 0ull;
-    wfq_trace_wave(a.sc, st, a.rq_o[par], a.rq_d[par], a.res[par], n_rays, &a.ctr[WFQ_C_CURSOR + par], claim, tests);
+    wfq_trace_wave(a.sc, st, a.rq_o[par], a.rq_d[par], a.res[par], a.n_region[par], (a.n_slots + BLOCK - 1u) / BLOCK, &a.ctr[WFQ_C_CURSOR + par], tests);
     for (int off = 32; off > 0; off >>= 1) tests += __shfl_down(tests, off, 64);
     if (lane_id() == 0u && tests) atomicAdd(&a.counters[3], tests);
 }
@@ -764,8 +766,8 @@ template <int INTEG>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3))) k_wfq_shade(WfqArgs a) {
     __shared__ uint2 sobol_tab[IRIS_SOBOL_LUT_ENTRIES];
     __shared__ float ring_lds[IRIS_RING_SLOTS * BLOCK];
-    __shared__ uint32_t wg_count[BLOCK / 64][3];
-    __shared__ uint32_t wg_base;
+    __shared__ uint32_t wg_count[BLOCK / 64][4], wg_got[BLOCK / 64];
+    __shared__ uint32_t run_next, run_lim, run_new;  // the workgroup's run of items
     stage_tables(sobol_tab);
     const SobolLds sobol_lds = sobol_tab;
     DrawRing ring = ring_lds + threadIdx.x;
@@ -778,16 +780,19 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     uint32_t n_live = 0u;
     const uint32_t n_tiles = (a.n_slots + BLOCK - 1u) / BLOCK, wave = threadIdx.x / 64u;
     const float inf = __builtin_inff();
+    if (threadIdx.x == 0u) {
+        const uint2 run = a.seed_pass ? make_uint2(0u, 0u) : a.wg_run[blockIdx.x];
+        run_next = run.x; run_lim = run.y; run_new = 0u;
+    }
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();  // wg_count / wg_base of the last tile have been read (and, the first time, the Sobol table is complete)
+        __syncthreads();  // the last tile's exchange has been read (and, the first time, the Sobol table and the run are in place)
         const uint32_t slot = tile * BLOCK + threadIdx.x;
         const bool in_range = slot < a.n_slots;
         uint4 A = make_uint4(0u, 0u, 0u, WFQ_NONE);
-        if (in_range && !a.seed_pass) A = a.st_a[slot];
+        float4 B = make_float4(0.0f, 1.0f, 0.0f, 0.0f), C = make_float4(0.0f, 0.0f, __uint_as_float(WFQ_NONE), __uint_as_float(WFQ_NONE));
+        if (in_range && !a.seed_pass) { A = a.st_a[slot]; B = a.st_b[slot]; C = a.st_c[slot]; }  // three independent loads: one round trip
         const uint32_t flags = A.y >> 16, state = flags & 3u;
         const bool is_ray = state == WFQ_RAY, live_in = is_ray || state == WFQ_FIN;
-        float4 B = make_float4(0.0f, 1.0f, 0.0f, 0.0f), C = make_float4(0.0f, 0.0f, __uint_as_float(WFQ_NONE), __uint_as_float(WFQ_NONE));
-        if (live_in) { B = a.st_b[slot]; C = a.st_c[slot]; }
         // ---- what the rays of the last pass found ----
         PathState ps;
         ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
@@ -834,24 +839,44 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
         bool cont = false;
         if (__ballot(hit) != 0ull) cont = shade_bounce<INTEG, IRIS_CLS_LAMBERT_CONSTANT, 2>(a.sc, st, a.fr, sobol_lds, ring, hit, ps, prim, t, cnt, &df);
         const bool go_on = hit && cont;
-        bool has_1 = hit && df.want1, has_2 = hit && df.has2;
-        const bool ended_now = hit && !cont && !has_1 && !has_2;  // nothing of this bounce is out: its direct light is complete
+        const bool ended_now = hit && !cont && !df.want1 && !df.has2;  // nothing of this bounce is out: its direct light is complete
         if (ended_now) apply_deferred(df, false, ps, false);
         // ---- finished paths: store the sample (tile.rs:159-162), then the lane starts the launch's next camera sample ----
         const bool ended = (live_in && !hit) || ended_now;
         if (ended) store_result(a, item, path_xyz<INTEG>(ps));
         const bool regen = ended || (in_range && a.seed_pass != 0u);
+        const bool has_1 = hit && df.want1, has_2 = hit && df.has2;
+        // ---- one exchange per tile through LDS: how many lanes of each wave want an item, and how many rays of each kind the
+        // waves will send (the extension rays of the paths that go on are known; those of new paths are known once the items
+        // are: a new path always sends one) ----
+        const unsigned long long m_regen = __ballot(regen), m_on = __ballot(go_on), m_1 = __ballot(has_1), m_2 = __ballot(has_2);
+        if (lane_id() == 0u) {
+            wg_count[wave][0] = (uint32_t)__popcll(m_regen); wg_count[wave][1] = (uint32_t)__popcll(m_on);
+            wg_count[wave][2] = (uint32_t)__popcll(m_1); wg_count[wave][3] = (uint32_t)__popcll(m_2);
+        }
+        __syncthreads();
+        // items: the workgroup hands out a run of consecutive items claimed from the launch's counter with one atomic per run
+        // (consecutive items = neighbouring pixels of one sample index); a tile that wants more than the run has left takes the
+        // rest of it and starts the next
+        uint32_t want_before = 0u, want_all = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < BLOCK / 64u; w++) { if (w < wave) want_before += wg_count[w][0]; want_all += wg_count[w][0]; }
+        const uint32_t old_next = run_next, old_left = run_lim - run_next;  // (LDS, stable between the barriers)
+        if (want_all > old_left) {
+            if (threadIdx.x == 0u) {
+                const unsigned long long start = atomicAdd(a.work_cursor, (unsigned long long)a.item_run);
+                run_new = start < (unsigned long long)a.n_items ? (uint32_t)start : a.n_items;  // past the end: an empty run at the end
+            }
+            __syncthreads();
+        }
         bool got = false;
         Ray ext = ps.ray;
-        if (__ballot(regen) != 0ull) {
-            const unsigned long long mask = __ballot(regen);
-            unsigned long long base = 0ull;
-            if (lane_id() == 0u) base = atomicAdd(a.work_cursor, (unsigned long long)__popcll(mask));
-            const uint32_t base_lo = __builtin_amdgcn_readfirstlane((uint32_t)base), base_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-            const unsigned long long id = (((unsigned long long)base_hi << 32) | base_lo) + prefix_below(mask);
-            got = regen && id < (unsigned long long)a.n_items;
+        if (regen) {
+            const uint32_t r = want_before + prefix_below(m_regen);
+            const uint32_t id = r < old_left ? old_next + r : run_new + (r - old_left);
+            got = id < a.n_items && (r < old_left || r - old_left < a.item_run);
             if (got) {
-                item = (uint32_t)id;
+                item = id;
                 const uint32_t s_local = fast_div(item, a.div_npix), pix = item - s_local * a.npix;
                 const uint32_t y = fast_div(pix, a.div_width), x = pix - y * a.fr.width;
                 const CamSample cs = camera_sample(a.cam, a.fr, sobol_lds, x, y, a.s_begin + s_local);
@@ -862,8 +887,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             }
         }
         if (go_on) cnt.rays++;  // the extension ray (counted by the other kernels when it comes back)
+        const unsigned long long m_got = __ballot(got);
+        if (lane_id() == 0u) wg_got[wave] = (uint32_t)__popcll(m_got);
+        __syncthreads();  // (also: every thread has read run_next / run_lim / run_new)
+        if (threadIdx.x == 0u) {
+            if (want_all > old_left) { run_next = min(run_new + (want_all - old_left), run_new + a.item_run); run_lim = run_new + a.item_run; if (run_new >= a.n_items) { run_next = run_lim = a.n_items; } }
+            else run_next = old_next + want_all;
+        }
         // ---- the rays of this pass: the spheres outside the tree and the root box here, with the whole wave busy ----
         const bool has_e = go_on || got;
+        const unsigned long long m_e = m_on | m_got;
         float4 e_o = {}, e_d = {}, q1_o = {}, q1_d = {}, q2_o = {}, q2_d = {};
         bool e_ans = false, q1_ans = false, q2_ans = false;
         float e_t = 0.0f, q1_t = 0.0f, q2_t = 0.0f;
@@ -871,28 +904,20 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
         if (has_e) wfq_prepare(a.sc, ext, false, inf, 0, e_o, e_d, e_ans, e_t, e_p, cnt.sphere_tests);
         if (has_1) wfq_prepare(a.sc, df.ray1, true, df.limit1, 0x7fffffff, q1_o, q1_d, q1_ans, q1_t, q1_p, cnt.sphere_tests);
         if (has_2) wfq_prepare(a.sc, df.ray2, true, df.limit2, df.tie2, q2_o, q2_d, q2_ans, q2_t, q2_p, cnt.sphere_tests);
-        const unsigned long long m_e = __ballot(has_e), m_1 = __ballot(has_1), m_2 = __ballot(has_2);
-        if (lane_id() == 0u) { wg_count[wave][0] = (uint32_t)__popcll(m_e); wg_count[wave][1] = (uint32_t)__popcll(m_1); wg_count[wave][2] = (uint32_t)__popcll(m_2); }
-        __syncthreads();
-        if (threadIdx.x == 0u) {
-            uint32_t total = 0u;
-            for (uint32_t w = 0; w < BLOCK / 64u; w++) total += wg_count[w][0] + wg_count[w][1] + wg_count[w][2];
-            wg_base = total ? atomicAdd(&a.ctr[WFQ_C_NRAYS + nxt], total) : 0u;
-        }
-        __syncthreads();
         uint32_t k_e = WFQ_NONE, k_1 = WFQ_NONE, k_2 = WFQ_NONE;
-        {   // queue order inside the workgroup's share: extension rays of waves 0..3, then the light-sample queries, then the others
-            uint32_t pos = wg_base, mine[3] = {0u, 0u, 0u};
+        {   // queue order inside the tile's region: extension rays of waves 0..3, then the light-sample queries, then the others
+            uint32_t pos = tile * IRIS_WFQ_REGION, mine[3] = {0u, 0u, 0u};
 #pragma unroll
             for (uint32_t kind = 0; kind < 3; kind++)
 #pragma unroll
                 for (uint32_t w = 0; w < BLOCK / 64u; w++) {
                     if (w == wave) mine[kind] = pos;
-                    pos += wg_count[w][kind];
+                    pos += kind == 0u ? wg_count[w][1] + wg_got[w] : wg_count[w][kind + 1u];
                 }
             if (has_e) k_e = mine[0] + prefix_below(m_e);
             if (has_1) k_1 = mine[1] + prefix_below(m_1);
             if (has_2) k_2 = mine[2] + prefix_below(m_2);
+            if (threadIdx.x == 0u) a.n_region[nxt][tile] = pos - tile * IRIS_WFQ_REGION;
         }
         if (has_e) { a.rq_o[nxt][k_e] = e_o; a.rq_d[nxt][k_e] = e_d; if (e_ans) a.res[nxt][k_e] = make_uint2(__float_as_uint(e_t), (uint32_t)e_p); }
         if (has_1) { a.rq_o[nxt][k_1] = q1_o; a.rq_d[nxt][k_1] = q1_d; if (q1_ans) a.res[nxt][k_1] = make_uint2(__float_as_uint(q1_t), (uint32_t)q1_p); }
@@ -917,6 +942,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
             if (nstate != WFQ_DEAD) { a.st_b[slot] = nB; a.st_c[slot] = nC; n_live++; }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0u) a.wg_run[blockIdx.x] = make_uint2(run_next, run_lim);
     flush_counters(a.counters, cnt);
     for (int off = 32; off > 0; off >>= 1) n_live += __shfl_down(n_live, off, 64);
     if (lane_id() == 0u && n_live) atomicAdd(&a.ctr[WFQ_C_LIVE + nxt], n_live);
@@ -1218,7 +1245,7 @@ struct iris_ctx {
     size_t stack_hi_words = 0;
     size_t xq_waves = 0;
     int64_t x_park_max = 24, x_fire = 110;
-    void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr;
+    void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr, *d_bvh_q = nullptr;
     void *d_env_texels = nullptr, *d_env_func = nullptr, *d_env_cond = nullptr, *d_env_marg = nullptr;
     float *d_up_coeff = nullptr, *d_up_scale = nullptr;  // UpsampleTable resident in HBM (iris_upsample_table_upload)
     uint32_t up_res = 0;
@@ -1236,12 +1263,13 @@ struct iris_ctx {
     unsigned long long *h_counters = nullptr;  // pinned: the work counters of a render are copied here
     unsigned char *scratch_ptr = nullptr;  // this device's copy of the static workspace (iris_render_device_noalloc)
     // queue kernels (k_wfq_*): up to WFQ_MAX_PIPES independent pipelines, each with its own slots, ray queues, counters and stream
-    int64_t wfq_slots = 4 << 20, wfq_pipes = 2, wfq_batch = 8;
+    int64_t wfq_slots = 4 << 20, wfq_pipes = 2, wfq_batch = 8, wfq_shade_per_cu = 16, wfq_trace_per_cu = 8, wfq_item_run = 1024;
     struct WfqPipe {
         uint4 *st_a = nullptr;
         float4 *st_b = nullptr, *st_c = nullptr, *rq_o[2] = {nullptr, nullptr}, *rq_d[2] = {nullptr, nullptr};
         uint2 *res[2] = {nullptr, nullptr};
-        uint32_t *ctr = nullptr, *stack_hi = nullptr, *h_ctr = nullptr;  // h_ctr: pinned
+        uint32_t *ctr = nullptr, *stack_hi = nullptr, *h_ctr = nullptr, *n_region[2] = {nullptr, nullptr};  // h_ctr: pinned
+        uint2 *wg_run = nullptr;
         size_t slots_cap = 0, stack_hi_words = 0;
         hipStream_t stream = nullptr;
         hipEvent_t ev = nullptr;
@@ -1376,8 +1404,8 @@ bool use_queue_kernels(const iris_ctx *c) {
 void free_wfq(iris_ctx *c) {
     for (auto &p : c->wfq) {
         dev_free(p.st_a); dev_free(p.st_b); dev_free(p.st_c);
-        for (int k = 0; k < 2; k++) { dev_free(p.rq_o[k]); dev_free(p.rq_d[k]); dev_free(p.res[k]); }
-        dev_free(p.ctr); dev_free(p.stack_hi);
+        for (int k = 0; k < 2; k++) { dev_free(p.rq_o[k]); dev_free(p.rq_d[k]); dev_free(p.res[k]); dev_free(p.n_region[k]); }
+        dev_free(p.ctr); dev_free(p.stack_hi); dev_free(p.wg_run);
         if (p.h_ctr) (void)hipHostFree(p.h_ctr);
         if (p.stream) (void)hipStreamDestroy(p.stream);
         if (p.ev) (void)hipEventDestroy(p.ev);
@@ -1399,11 +1427,16 @@ int ensure_wfq(iris_ctx *c, int n_pipes, size_t slots, size_t stack_hi_words) {
         if (p.slots_cap < slots) {
             dev_free(p.st_a); dev_free(p.st_b); dev_free(p.st_c);
             p.st_a = nullptr; p.st_b = p.st_c = nullptr;
-            for (int k = 0; k < 2; k++) { dev_free(p.rq_o[k]); dev_free(p.rq_d[k]); dev_free(p.res[k]); p.rq_o[k] = p.rq_d[k] = nullptr; p.res[k] = nullptr; }
+            for (int k = 0; k < 2; k++) { dev_free(p.rq_o[k]); dev_free(p.rq_d[k]); dev_free(p.res[k]); dev_free(p.n_region[k]); p.rq_o[k] = p.rq_d[k] = nullptr; p.res[k] = nullptr; p.n_region[k] = nullptr; }
+            dev_free(p.wg_run);
+            p.wg_run = nullptr;
             p.slots_cap = 0;
             if ((rc = dev_alloc(c, &p.st_a, slots)) || (rc = dev_alloc(c, &p.st_b, slots)) || (rc = dev_alloc(c, &p.st_c, slots))) return rc;
             for (int k = 0; k < 2; k++)  // a slot sends at most three rays per pass
-                if ((rc = dev_alloc(c, &p.rq_o[k], 3 * slots)) || (rc = dev_alloc(c, &p.rq_d[k], 3 * slots)) || (rc = dev_alloc(c, &p.res[k], 3 * slots))) return rc;
+                if ((rc = dev_alloc(c, &p.rq_o[k], 3 * slots)) || (rc = dev_alloc(c, &p.rq_d[k], 3 * slots)) || (rc = dev_alloc(c, &p.res[k], 3 * slots)) ||
+                    (rc = dev_alloc(c, &p.n_region[k], slots / BLOCK)))
+                    return rc;
+            if ((rc = dev_alloc(c, &p.wg_run, slots / BLOCK))) return rc;  // one per workgroup of k_wfq_shade: at most one per tile
             p.slots_cap = slots;
         }
         if (p.stack_hi_words < stack_hi_words) {
@@ -1425,8 +1458,10 @@ int run_wfq(iris_ctx *c, const WfArgs &a, hipStream_t stream) {
     while (n_pipes > 1 && tiles_needed < (uint32_t)n_pipes * 64u) n_pipes--;  // small renders: one pipeline
     const size_t cap = std::max<size_t>(BLOCK, ((size_t)c->wfq_slots / n_pipes) & ~(size_t)(BLOCK - 1));
     const size_t slots = std::min<size_t>(cap, (size_t)((tiles_needed + n_pipes - 1) / n_pipes) * BLOCK);
-    const uint32_t trace_blocks = (uint32_t)c->n_cus * 8u, lds_n = std::min<uint32_t>(std::max<uint32_t>(c->bvh_depth, 1u), WFQ_STACK_LDS);
-    const uint32_t shade_blocks = std::min<uint32_t>((uint32_t)(slots / BLOCK), (uint32_t)c->n_cus * 6u);
+    const uint32_t trace_blocks = (uint32_t)c->n_cus * (uint32_t)c->wfq_trace_per_cu, lds_n = std::min<uint32_t>(std::max<uint32_t>(c->bvh_depth, 1u), WFQ_STACK_LDS);
+    int shade_per_cu = 0;  // the shade kernel deals its tiles in advance: exactly the workgroups that are resident at once
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&shade_per_cu, k_wfq_shade<INTEG>, BLOCK, 0) != hipSuccess || shade_per_cu < 1) shade_per_cu = 3;
+    const uint32_t shade_blocks = std::min<uint32_t>((uint32_t)(slots / BLOCK), (uint32_t)c->n_cus * (uint32_t)std::min<int64_t>(shade_per_cu, c->wfq_shade_per_cu));
     const size_t stack_hi_words = c->bvh_depth > lds_n ? (size_t)trace_blocks * BLOCK * (c->bvh_depth - lds_n) : 1;
     int rc;
     if ((rc = ensure_wfq(c, n_pipes, slots, stack_hi_words))) return rc;
@@ -1444,7 +1479,8 @@ int run_wfq(iris_ctx *c, const WfArgs &a, hipStream_t stream) {
         w.work_cursor = a.work_cursor;
         w.npix = a.npix; w.div_npix = a.div_npix; w.div_width = a.div_width;
         w.s_begin = a.s_begin; w.n_items = a.n_items; w.n_slots = (uint32_t)slots;
-        w.par = 0u; w.seed_pass = 1u;
+        w.par = 0u; w.seed_pass = 1u; w.item_run = (uint32_t)c->wfq_item_run;
+        w.n_region[0] = p.n_region[0]; w.n_region[1] = p.n_region[1]; w.wg_run = p.wg_run;
         w.stack_hi = p.stack_hi;
         w.stack_lds_n = lds_n;
         HIP_TRY(c, hipStreamWaitEvent(p.stream, c->wfq_ev_start, 0));
@@ -1786,6 +1822,17 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
                      (double)t[15] / (double)std::max(1ull, t[11]), (double)t[16] / (double)std::max(1ull, t[11]));
     }
 #endif
+#ifdef IRIS_WFQ_STATS
+    if (wfq) {
+        unsigned long long g[8] = {};
+        (void)hipMemcpyFromSymbol(g, HIP_SYMBOL(g_wfq_stats), sizeof g);
+        std::fprintf(stderr, "[wfq trace] rays %llu | fetches %llu (%.1f rays each) | rounds %llu, lanes holding a ray %.1f | inner rounds %llu, lanes per step %.1f (steps %.3g) | leaf rounds %llu, lanes %.1f\n",
+                     g[1], g[0], (double)g[1] / std::max(1ull, g[0]), g[6], (double)g[7] / std::max(1ull, g[6]), g[2], (double)g[3] / std::max(1ull, g[2]) / IRIS_WFQ_INNER_REPS, (double)g[3],
+                     g[4], (double)g[5] / std::max(1ull, g[4]));
+        unsigned long long z[8] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wfq_stats), z, sizeof z);
+    }
+#endif
     c->stats.samples = h[0];
     c->stats.bounces = h[1];
     c->stats.rays = h[2];
@@ -1832,7 +1879,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     free_pools(c);
     free_wfq(c);
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind); dev_free(c->d_light_rec);
-    dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
+    dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim); dev_free(c->d_bvh_q);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     dev_free(c->d_up_coeff); dev_free(c->d_up_scale);
     dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_park); dev_free(c->d_sky); dev_free(c->d_work_cursor);
@@ -1891,6 +1938,12 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "wfq_pipes") {
         if (value < 1 || value > WFQ_MAX_PIPES) return fail(c, IRIS_E_ARG, "wfq_pipes out of range [1, 4]");
         c->wfq_pipes = value;
+    } else if (k == "wfq_shade_per_cu" || k == "wfq_trace_per_cu") {
+        if (value < 1 || value > 16) return fail(c, IRIS_E_ARG, k + " out of range [1, 16]");
+        (k == "wfq_shade_per_cu" ? c->wfq_shade_per_cu : c->wfq_trace_per_cu) = value;
+    } else if (k == "wfq_item_run") {
+        if (value < BLOCK || value > (1 << 20)) return fail(c, IRIS_E_ARG, "wfq_item_run out of range [256, 2^20]");
+        c->wfq_item_run = value;
     } else if (k == "wfq_batch") {
         if (value < 1 || value > 1024) return fail(c, IRIS_E_ARG, "wfq_batch out of range [1, 1024]");
         c->wfq_batch = value;
@@ -1941,11 +1994,11 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     dev_free(c->d_spheres); dev_free(c->d_prim_info); dev_free(c->d_bsdfs); dev_free(c->d_spectra); dev_free(c->d_lights); dev_free(c->d_spec_over_pi); dev_free(c->d_prim_kind); dev_free(c->d_light_rec);
     c->d_spec_over_pi = nullptr;
     c->d_prim_kind = nullptr;
-    dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim);
+    dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim); dev_free(c->d_bvh_q);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     c->d_env_texels = c->d_env_func = c->d_env_cond = c->d_env_marg = nullptr;
     c->d_spheres = c->d_prim_info = c->d_bsdfs = c->d_spectra = c->d_lights = c->d_light_rec = nullptr;
-    c->d_bvh_nodes = c->d_bvh_spheres = c->d_bvh_prim = nullptr;
+    c->d_bvh_nodes = c->d_bvh_spheres = c->d_bvh_prim = c->d_bvh_q = nullptr;
     c->sc = SceneDev{};
     c->have_scene = false;
     // per primitive: (material, light, albedo / PI of a Lambertian material over a constant spectrum -- lambertian.rs:30, one IEEE
@@ -2004,9 +2057,14 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
         Bvh bvh;
         if (build_bvh(s->spheres, s->n_prims, (uint32_t)c->bvh_leaf, bvh)) {
             HIP_TRY(c, up(&c->d_bvh_nodes, bvh.nodes.data(), sizeof(float4) * bvh.nodes.size()));
+            HIP_TRY(c, up(&c->d_bvh_q, bvh.qnodes.data(), sizeof(uint32_t) * bvh.qnodes.size()));
             HIP_TRY(c, up(&c->d_bvh_spheres, bvh.spheres.data(), sizeof(float4) * bvh.spheres.size()));
             HIP_TRY(c, up(&c->d_bvh_prim, bvh.prim.data(), sizeof(uint32_t) * bvh.prim.size()));
             c->sc.bvh_nodes = (const float4 *)c->d_bvh_nodes;
+            c->sc.bvh_q = (const uint4 *)c->d_bvh_q;
+            for (int k = 0; k < 3; k++) c->sc.bvh_g0[k] = bvh.grid_origin[k];
+            c->sc.bvh_s = bvh.grid_scale;
+            c->sc.bvh_inv_s = bvh.grid_inv_scale;
             c->sc.bvh_spheres = (const float4 *)c->d_bvh_spheres;
             c->sc.bvh_prim = (const uint32_t *)c->d_bvh_prim;
             c->sc.n_bvh_nodes = (uint32_t)(bvh.nodes.size() / 2);
