@@ -187,8 +187,11 @@ const char *iris_last_error(const iris_ctx *ctx);
  *                     2: register-resident kernel (needs the sphere list to fit the LDS window, or a hierarchy);
  *                     3: queue kernels (shading and traversal as separate kernels over path-state and ray queues in HBM;
  *                     needs a hierarchy and a scene of Lambertian BSDFs over constant spectra, for which mode 0 chooses it)
- *   "wfq_slots"       queue kernels: path-state slots in all (default 4194304; a multiple of 256)
- *   "wfq_pipes"       queue kernels: independent pipelines on streams of their own that share the slots (1..4, default 2)
+ *   "wfq_slots"       queue kernels: path-state slots in all (default 12582912; a multiple of 256)
+ *   "wfq_pipes"       queue kernels: independent pipelines on streams of their own that share the slots (1..4, default 3)
+ *   "wfq_batch"       queue kernels: shade/trace passes enqueued between two looks at the number of live paths (default 8)
+ *   "wfq_trace_per_cu", "wfq_shade_per_cu"  queue kernels: workgroups per CU of the two kernels (defaults 3 and 2)
+ *   "wfq_item_run"    queue kernels: items a workgroup claims at a time from the launch's counter (default 1024)
  *   "work_run"          register-resident kernel: items a wave claims at a time from the launch's counter (0 = auto, default)
  *   "reg_blocks_per_cu" register-resident kernel: workgroups per CU in the grid (default 8: at least what a CU holds; items are claimed from one global counter)
  *   "bvh_min_prims"   scenes with at least this many spheres get a bounding-volume hierarchy at upload and the

@@ -147,6 +147,30 @@ bool build_bvh(const iris_sphere *sp, uint32_t n, uint32_t leaf, Bvh &out) {
         if (out.depth <= IRIS_BVH_STACK) { order = work; break; }
         if (attempt == 1) return false;
     }
+    // Nodes in breadth-first order: the top of the tree, which every ray walks, becomes a prefix of the arrays (k_wfq_trace keeps
+    // that prefix in LDS).  Children stay adjacent pairs (k, k + 1) with k odd.
+    {
+        const size_t n_nodes = out.nodes.size() / 2;
+        std::vector<Float4> bfs(out.nodes.size());
+        std::vector<uint32_t> queue_old(1, 0u);  // old index of the node that gets new index i
+        queue_old.reserve(n_nodes);
+        for (size_t i = 0; i < queue_old.size(); i++) {
+            Float4 lo = out.nodes[2 * queue_old[i]], hi = out.nodes[2 * queue_old[i] + 1];
+            uint32_t first, count;
+            std::memcpy(&first, &lo.w, 4);
+            std::memcpy(&count, &hi.w, 4);
+            if (count == 0u) {  // inner node: its children take the next two indices
+                const uint32_t left_new = (uint32_t)queue_old.size();
+                queue_old.push_back(first);
+                queue_old.push_back(first + 1u);
+                std::memcpy(&lo.w, &left_new, 4);
+            }
+            bfs[2 * i] = lo;
+            bfs[2 * i + 1] = hi;
+        }
+        if (queue_old.size() != n_nodes) return false;
+        out.nodes.swap(bfs);
+    }
     // the 16-bit grid records (iris_bvh_build.h): grid over the root box, four units of margin below, the scale a little over
     // extent / 65528 so that every upper bound stays below 65535 after its outward rounding and the extra unit
     {

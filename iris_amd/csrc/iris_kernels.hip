@@ -1263,7 +1263,10 @@ struct iris_ctx {
     unsigned long long *h_counters = nullptr;  // pinned: the work counters of a render are copied here
     unsigned char *scratch_ptr = nullptr;  // this device's copy of the static workspace (iris_render_device_noalloc)
     // queue kernels (k_wfq_*): up to WFQ_MAX_PIPES independent pipelines, each with its own slots, ray queues, counters and stream
-    int64_t wfq_slots = 4 << 20, wfq_pipes = 2, wfq_batch = 8, wfq_shade_per_cu = 16, wfq_trace_per_cu = 8, wfq_item_run = 1024;
+    // Measured on config D (ms per launch): 2 pipelines x 2 Mi slots, 8 + 4 workgroups per CU 121.1; 3 x 4 Mi, 3 + 2 112.9 (3 x 8 Mi 120.6, 4 x 4 Mi
+    // 133.1, shade 1 per CU 119.4, trace 4 per CU 121.5): fewer resident workgroups per kernel leave room for another pipeline's
+    // kernel on the same CU, which is what overlaps the latency-bound shade passes with the traversal
+    int64_t wfq_slots = 12 << 20, wfq_pipes = 3, wfq_batch = 8, wfq_shade_per_cu = 2, wfq_trace_per_cu = 3, wfq_item_run = 1024;
     struct WfqPipe {
         uint4 *st_a = nullptr;
         float4 *st_b = nullptr, *st_c = nullptr, *rq_o[2] = {nullptr, nullptr}, *rq_d[2] = {nullptr, nullptr};
@@ -1397,7 +1400,7 @@ bool use_register_kernel(const iris_ctx *c) {
 // The queue kernels serve scenes with a hierarchy whose BSDFs are Lambertian over constant spectra (one value for the four
 // wavelengths: 48 bytes of path state); mode 0 chooses them there, mode 2 keeps the register-resident kernel.
 bool use_queue_kernels(const iris_ctx *c) {
-    if (c->multi_kernel || c->mode != 3) return false;  // opt-in until it beats the pooled traversal of k_regwave
+    if (c->multi_kernel || !(c->mode == 0 || c->mode == 3)) return false;  // mode 0: config D 112.9 ms against 118.8 ms for k_regwave's pooled traversal
     return c->sc.n_bvh_nodes != 0u && c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;
 }
 

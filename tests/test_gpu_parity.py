@@ -483,11 +483,12 @@ def test_many_spheres_scene_counters(gpu, gpu_list, iris_trig):
     assert np.array_equal(bits(film_h), bits(want))
     gh = gpu.stats()
     assert (gh.rays, gh.bounces) == (st.rays, st.bounces) and gh.sphere_tests < st.sphere_tests // 50
-    assert gh.kernel == 2  # register-resident kernel
-    with iris_amd.HipWavefront(0, mode=1) as g2:
-        g2.upload(scene)
-        assert np.array_equal(bits(g2.render_film(Render(40, 24, 2, scene))), bits(want))
-        assert g2.stats().kernel == 0 and g2.stats().sphere_tests == gh.sphere_tests
+    assert gh.kernel == 3  # the queue kernels (this scene class under a hierarchy)
+    for mode, kernel in ((1, 0), (2, 2)):  # the pool kernels and the register-resident kernel (pooled traversal): same tree, same steps per ray
+        with iris_amd.HipWavefront(0, mode=mode) as g2:
+            g2.upload(scene)
+            assert np.array_equal(bits(g2.render_film(Render(40, 24, 2, scene))), bits(want))
+            assert g2.stats().kernel == kernel and g2.stats().sphere_tests == gh.sphere_tests
 
 
 def test_hierarchy_never_culls_what_the_f32_sphere_test_reports(gpu, gpu_list, iris_trig):
@@ -538,13 +539,14 @@ def test_every_leaf_size_gives_the_list_scan_film(gpu_list, specialize):
     want = gpu_list.render_film(r)
     ws = gpu_list.stats()
     for leaf in (1, 2, 3, 4, 7):
-        with iris_amd.HipWavefront(device=0, bvh_leaf=leaf, specialize=specialize) as ctx:
-            ctx.upload(scene)
-            film = ctx.render_film(r)
-            st = ctx.stats()
-            assert st.bvh_depth > 0
-            assert np.array_equal(bits(film), bits(want)), leaf
-            assert (st.samples, st.bounces, st.rays) == (ws.samples, ws.bounces, ws.rays), leaf
+        for mode in ((0, 2) if specialize else (0,)):  # specialised class: the queue kernels (mode 0) and k_regwave's pooled traversal (mode 2)
+            with iris_amd.HipWavefront(device=0, bvh_leaf=leaf, specialize=specialize, mode=mode) as ctx:
+                ctx.upload(scene)
+                film = ctx.render_film(r)
+                st = ctx.stats()
+                assert st.bvh_depth > 0
+                assert np.array_equal(bits(film), bits(want)), (leaf, mode)
+                assert (st.samples, st.bounces, st.rays) == (ws.samples, ws.bounces, ws.rays), (leaf, mode)
 
 
 def test_list_scan_films_of_long_lists(gpu_list, iris_trig):
