@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""A SECOND, independent restatement of one camera sample through HwssNaive on the reference's default scene, in numpy
-float32 scalars -- written from the Rust text (64/iris @ 2025-01-03, src/), not from oracle/iris_oracle.c and not from the
-kernels: tile.rs:127-166, integrator/hwss_naive.rs:28-157, scene.rs:43-66,116-172, shape/sphere.rs:25-162,
-shape/mod.rs:24-37, bsdf/lambertian.rs:23-51, math/ray.rs:14-85, math/vec3.rs:45-96, math/matrix.rs:168-196,
-sampling/mod.rs:22-59, sampling/sampler.rs:13-88, sampling/mis.rs:3-10, spectrum/wavelength.rs:14-64,
-spectrum/sample.rs:45-52, spectrum/constant.rs:15-23, color.rs:21-34.
+"""A SECOND, independent restatement of one camera sample, in numpy float32 scalars -- written from the Rust text (64/iris @
+2025-01-03, src/), not from oracle/iris_oracle.c and not from the kernels: tile.rs:127-166, integrator/hwss_naive.rs:28-157,
+integrator/swss_naive.rs:28-153, scene.rs:43-66,116-172, shape/sphere.rs:25-162, shape/mod.rs:24-37, bsdf/lambertian.rs:23-51,
+bsdf/microfacet.rs:32-93, bsdf/specular.rs:25-54, bsdf/fresnel.rs:30-107, sampling/ggx.rs:7-77, math/mod.rs:35-72,
+math/ray.rs:14-85, math/vec3.rs:45-111,301-355, math/matrix.rs:168-196, sampling/mod.rs:22-59, sampling/sampler.rs:13-88,
+sampling/mis.rs:3-10, spectrum/wavelength.rs:14-64, spectrum/sample.rs:45-52, spectrum/constant.rs:15-23, color.rs:21-34.
+
+Two sets of traces: HwssNaive on the reference's default scene (Lambertian only; traces_s1_restated.npz), and HwssNaive and
+SwssNaive on the glossy/dielectric scene S3 at depth 32 (GGX microfacet, mirror, dispersive dielectric; traces_s3_restated.npz).
 
 Taken as given (they are this build's definitions, docs/SPEC.md sections 4 and 5, because the reference leaves them to a
 crate and to libm): the Sobol points and sin/cos.  Both are implemented here from the SPEC's text -- the direction vectors
 straight from scipy's Joe-Kuo table, the f64 fused multiply-adds in exact rational arithmetic -- so this file shares no code
-with the oracle either.  The camera matrix (camera.rs:10-21: one tan() from libm) and the colour-matching tables
-(color.rs:145-1565: data) are inputs.
+with the oracle either.  The camera matrix (camera.rs:10-21: one tan() from libm), the GGX alpha of the S3 scene's rough sphere
+(ggx.rs:66-73: one ln() from libm, evaluated once when the scene is built) and the colour-matching tables (color.rs:145-1565:
+data) are inputs.
 
-    python tests/golden/restate_path.py          # writes tests/golden/traces_s1_restated.npz
+    python tests/golden/restate_path.py          # writes tests/golden/traces_s1_restated.npz and traces_s3_restated.npz
 
 tests/test_oracle.py checks the oracle against the file, tests/test_gpu_parity.py the GPU: a misreading of the Rust text
 would now have to be made the same way twice, by two different programs, to go unnoticed.
@@ -148,6 +152,10 @@ def hash_u32(n, seed):  # :74-83
     return h
 
 
+def hash_u32_to_f32(n, seed):  # :85-88: INV_MAX = 1.0 / u32::MAX as f32 = 2^-32
+    return F(hash_u32(n, seed)) * (ONE / F(4294967296.0))
+
+
 class Sampler:  # :4-72
     def __init__(self, x, y, sample_index, seed):
         self.scramble = hash_u32((x & M32) ^ ((y << 16) & M32), seed)
@@ -162,8 +170,10 @@ class Sampler:  # :4-72
         if self.in_buf > 0:
             self.in_buf -= 1
             return self.buf[self.in_buf]
-        assert self.dimension < 64, "past this build's Sobol table (docs/SPEC.md section 4)"
-        self.buf = sobol_sample_4d(self.index, self.dimension, hash_u32(self.dimension, self.scramble))
+        if self.dimension < 64:  # sobol::NUM_DIMENSIONS in units of 4-D sets (docs/SPEC.md section 4)
+            self.buf = sobol_sample_4d(self.index, self.dimension, hash_u32(self.dimension, self.scramble))
+        else:                    # :36-41
+            self.buf = [hash_u32_to_f32(((self.dimension + k) & M32) ^ ((self.index << 16) & M32), self.scramble) for k in range(4)]
         self.dimension += 1
         self.in_buf = 3
         return self.buf[3]
@@ -196,6 +206,8 @@ class V:
     def len(self): return np.sqrt(self.len_squared())
     def normalize(self): return self.div(self.len())                        # vec3.rs:67-70
     def tolist(self): return [self.x, self.y, self.z]
+    def is_zero(self): return bool(self.x == ZERO and self.y == ZERO and self.z == ZERO)   # Vec3 == Vec3::splat(0.0), vec3.rs:139-144
+    def face_forward(self, n): return self if self.dot(n) >= ZERO else -self               # vec3.rs:105-111
 
 
 def coordinate_system_from_unit(s):  # vec3.rs:77-85
@@ -220,6 +232,61 @@ def fmin(a, b):
     if b != b:
         return a
     return b if b < a else a
+
+
+def clamp(x, lo, hi):  # f32::clamp: NaN stays NaN
+    return lo if x < lo else (hi if x > hi else x)
+
+
+# shading-space trigonometry, vec3.rs:301-355
+def cos_theta(w): return w.z
+def cos_2_theta(w): return w.z * w.z
+def sin_2_theta(w): return fmax(ONE - cos_2_theta(w), ZERO)
+def sin_theta(w): return np.sqrt(sin_2_theta(w))
+def tan_theta(w): return sin_theta(w) / cos_theta(w)
+def tan_2_theta(w): return sin_2_theta(w) / cos_2_theta(w)
+
+
+def cos_phi(w):
+    st = sin_theta(w)
+    return ZERO if st == ZERO else clamp(w.x / st, F(-1.0), ONE)
+
+
+def sin_phi(w):
+    st = sin_theta(w)
+    return ZERO if st == ZERO else clamp(w.y / st, F(-1.0), ONE)
+
+
+def cos_2_phi(w): return cos_phi(w) * cos_phi(w)
+def sin_2_phi(w): return sin_phi(w) * sin_phi(w)
+def same_hemisphere(a, b): return bool(a.z * b.z > ZERO)
+
+
+# ------------------------------------------------------------------ math/mod.rs
+def fresnel_dielectric(cos_theta_i, eta_i, eta_t):  # :35-59
+    cos_theta_i = clamp(cos_theta_i, F(-1.0), ONE)
+    if cos_theta_i > ZERO:
+        ei, et, ci = eta_i, eta_t, cos_theta_i
+    else:
+        ei, et, ci = eta_t, eta_i, abs(cos_theta_i)
+    sin_theta_i = np.sqrt(fmax(ONE - ci * ci, ZERO))
+    sin_theta_t = ei / et * sin_theta_i
+    if sin_theta_t >= ONE:
+        return ONE
+    cos_theta_t = np.sqrt(fmax(ONE - sin_theta_t * sin_theta_t, ZERO))
+    r_par = ((et * ci) - (ei * cos_theta_t)) / ((et * ci) + (ei * cos_theta_t))
+    r_perp = ((ei * ci) - (et * cos_theta_t)) / ((ei * ci) + (et * cos_theta_t))
+    return (r_par * r_par + r_perp * r_perp) / TWO
+
+
+def refract(wi, n, eta):  # :61-72
+    cos_theta_i = n.dot(wi)
+    sin_2_theta_i = fmax(ONE - cos_theta_i * cos_theta_i, ZERO)
+    sin_2_theta_t = eta * eta * sin_2_theta_i
+    if sin_2_theta_t >= ONE:
+        return None
+    cos_theta_t = np.sqrt(ONE - sin_2_theta_t)
+    return (-wi).scale(eta) + n.scale(eta * cos_theta_i - cos_theta_t)
 
 
 # ------------------------------------------------------------------ math/ray.rs
@@ -369,18 +436,19 @@ def balance_heuristic_1(f): return f[0] / sum4(f)               # mis.rs:3-5
 def balance_heuristic_2(f, g): return f[0] / sum4(add4(f, g))   # mis.rs:8-10
 
 
-# ------------------------------------------------------------------ bsdf/lambertian.rs over spectrum/constant.rs
+# ------------------------------------------------------------------ bsdf/*.rs over spectrum/constant.rs
+# Every spectrum of the two scenes is a ConstantSpectrum (constant.rs:15-23): its value at each of the four wavelengths.
 class Lambertian:
     def __init__(self, albedo):
         self.albedo = F(albedo)
 
-    def evaluate(self):  # :24-31: albedo.evaluate(lambda) / PI; a ConstantSpectrum is its value at every wavelength
+    def evaluate(self, wi, wo, wl):  # lambertian.rs:24-31: albedo.evaluate(lambda) / PI
         return div4s(splat(self.albedo), PI)
 
-    def pdf(self, wi):   # :33-35 + sampling/mod.rs:56-59
+    def pdf(self, wi, wo):           # :33-35 + sampling/mod.rs:56-59
         return splat(abs(wi.z) / PI)
 
-    def sample(self, wo, smp):  # :37-50; arguments are evaluated left to right: the first draw is r1
+    def sample(self, wo, wl, smp):   # :37-50; arguments are evaluated left to right: the first draw is r1
         r1 = smp.gen_0_1()
         r2 = smp.gen_0_1()
         x_off, y_off = TWO * r1 - ONE, TWO * r2 - ONE       # concentric_disk, sampling/mod.rs:33-47
@@ -397,7 +465,110 @@ class Lambertian:
         wi = V(x, y, z)
         if not (wo.z * wi.z > ZERO):                        # same_hemisphere, vec3.rs:352-354
             wi = -wi
-        return wi, self.evaluate(), self.pdf(wi)
+        return wi, self.evaluate(wi, wo, wl), self.pdf(wi, wo)
+
+
+# sampling/ggx.rs
+def ggx_sample(wo, ax, ay, smp):  # :7-33
+    wo = V(ax * wo.x, ay * wo.y, wo.z).normalize()
+    len_2 = wo.x * wo.x + wo.y * wo.y
+    t1_v = V(-wo.y, wo.x, ZERO).div(np.sqrt(len_2)) if len_2 > ZERO else V(ONE, ZERO, ZERO)
+    t2_v = wo.cross(t1_v)
+    r = np.sqrt(smp.gen_0_1())
+    phi = TWO * PI * smp.gen_0_1()
+    sphi, cphi = sincos(phi)
+    t1 = r * cphi
+    t2 = r * sphi
+    s = HALF * (ONE + wo.z)
+    t2 = (ONE - s) * np.sqrt(ONE - t1 * t1) + s * t2
+    nh = (t1_v.scale(t1) + t2_v.scale(t2)) + wo.scale(np.sqrt(fmax(ONE - t1 * t1 - t2 * t2, ZERO)))
+    return V(ax * nh.x, ay * nh.y, fmax(nh.z, ZERO)).normalize()
+
+
+def ggx_evaluate(wh, ax, ay):  # :35-43
+    if np.isinf(tan_2_theta(wh)):
+        return ZERO
+    e = (cos_2_phi(wh) / (ax * ax) + sin_2_phi(wh) / (ay * ay)) * tan_2_theta(wh)
+    c2 = cos_theta(wh) * cos_theta(wh)                       # powi(4) = (x * x) * (x * x)
+    return ONE / (PI * ax * ay * (c2 * c2) * ((ONE + e) * (ONE + e)))
+
+
+def ggx_lambda(w, ax, ay):  # :45-55
+    if np.isinf(tan_theta(w)):
+        return ZERO
+    alpha = np.sqrt(cos_2_phi(w) * (ax * ax) + sin_2_phi(w) * (ay * ay))
+    a = alpha * abs(tan_theta(w))
+    return (F(-1.0) + np.sqrt(ONE + a * a)) / TWO
+
+
+def ggx_g(wo, wh, ax, ay): return ONE / (ONE + ggx_lambda(wh, ax, ay) + ggx_lambda(wo, ax, ay))   # :57-59
+def ggx_g1(w, ax, ay): return ONE / (ONE + ggx_lambda(w, ax, ay))                                 # :75-77
+def ggx_pdf(wo, wh, ax, ay): return ggx_evaluate(wh, ax, ay) * ggx_g1(wo, ax, ay) * abs(wo.dot(wh)) / abs(cos_theta(wo))  # :61-64
+
+
+class Microfacet:  # bsdf/microfacet.rs
+    def __init__(self, reflectance, alpha_x, alpha_y):
+        self.reflectance, self.ax, self.ay = F(reflectance), F(alpha_x), F(alpha_y)
+
+    def evaluate(self, wi, wo, wl):  # :33-57
+        cos_theta_o, cos_theta_i = abs(cos_theta(wo)), abs(cos_theta(wi))
+        wh = wo + wi
+        if not same_hemisphere(wi, wo) or cos_theta_o == ZERO or cos_theta_i == ZERO or wh.is_zero():
+            return splat(0.0)
+        wh = wh.normalize()
+        wh_facing = wh.face_forward(V(ZERO, ZERO, ONE))
+        d = ggx_evaluate(wh, self.ax, self.ay)
+        f = fresnel_dielectric(wi.dot(wh_facing), F(1.5), ONE)
+        g = ggx_g(wo, wh, self.ax, self.ay)
+        return div4s(scale4(scale4(scale4(splat(self.reflectance), d), g), f), F(4.0) * cos_theta_o * cos_theta_i)
+
+    def pdf(self, wi, wo):           # :59-63
+        wh = (wi + wo).normalize()
+        return splat(ggx_pdf(wo, wh, self.ax, self.ay) / (F(4.0) * wo.dot(wh)))
+
+    def sample(self, wo, wl, smp):   # :65-88
+        wh = ggx_sample(wo, self.ax, self.ay, smp)
+        wi = (-wo) + wh.scale(TWO * wo.dot(wh))              # reflect, :91-93: -wo + (2.0 * wo.dot(n) * n)
+        if cos_theta(wo) == ZERO or wo.dot(wh) < ZERO or not same_hemisphere(wo, wi):
+            return V(ZERO, ZERO, ZERO), splat(0.0), splat(0.0)
+        pdf = ggx_pdf(wo, wh, self.ax, self.ay) / (F(4.0) * wo.dot(wh))
+        return wi, self.evaluate(wi, wo, wl), splat(pdf)
+
+
+class Specular:  # bsdf/specular.rs
+    def __init__(self, reflected):
+        self.reflected = F(reflected)
+
+    def evaluate(self, wi, wo, wl): return splat(0.0)        # :26-33
+    def pdf(self, wi, wo): return splat(0.0)                 # :35-37
+
+    def sample(self, wo, wl, smp):   # :39-49: no draw
+        wi = V(-wo.x, -wo.y, wo.z)
+        return wi, div4s(splat(self.reflected), abs(cos_theta(wi))), splat(1.0)
+
+
+class Fresnel:  # bsdf/fresnel.rs
+    def __init__(self, reflected, transmitted, base_ior, dispersion):
+        self.reflected, self.transmitted, self.base_ior, self.dispersion = F(reflected), F(transmitted), F(base_ior), F(dispersion)
+
+    def evaluate(self, wi, wo, wl): return splat(0.0)        # :37-44
+    def pdf(self, wi, wo): return splat(0.0)                 # :46-48
+
+    def sample(self, wo, wl, smp):   # :50-102
+        eta_a = ONE
+        eta_b = [self.base_ior + self.dispersion / ((w * w) * F(1e-6)) for w in wl]   # :30-34
+        fresnel = [fresnel_dielectric(cos_theta(wo), eta_a, e) for e in eta_b]
+        if smp.gen_0_1() < fresnel[0]:
+            wi = V(-wo.x, -wo.y, wo.z)
+            bsdf = div4s(splat(self.reflected), abs(cos_theta(wi)))
+            return wi, mul4(bsdf, fresnel), list(fresnel)
+        eta_i, eta_t = (eta_a, eta_b[0]) if cos_theta(wo) > ZERO else (eta_b[0], eta_a)
+        wi = refract(wo, V(ZERO, ZERO, ONE).face_forward(wo), eta_i / eta_t)
+        if wi is None:               # total internal reflection
+            return V(ZERO, ZERO, ZERO), splat(0.0), splat(0.0)
+        ft = div4s(scale4(scale4(splat(self.transmitted), ONE - fresnel[0]), eta_i * eta_i), eta_t * eta_t)
+        hero_value = ft[0] / abs(cos_theta(wi))
+        return wi, [hero_value, ZERO, ZERO, ZERO], [ONE - fresnel[0], ZERO, ZERO, ZERO]
 
 
 # ------------------------------------------------------------------ scene.rs
@@ -414,6 +585,17 @@ def default_scene():  # Scene::dummy, scene.rs:43-66
     return prims, lights
 
 
+def glossy_dielectric_scene(alpha):
+    """S3 (iris_amd.Scene.glossy_dielectric): the default scene with the middle sphere a dispersive dielectric
+    (the values in the comment at scene.rs:55-60), a GGX sphere (roughness 0.2 -> `alpha`, ggx.rs:66-73) and a mirror sphere"""
+    prims = [Prim(Sphere((0.0, 2.3, 3.0), 1.0), Lambertian(0.5), F(3.0)),
+             Prim(Sphere((0.0, -0.2, 3.0), 1.0), Fresnel(1.0, 1.0, 1.5220, 0.00459), None),
+             Prim(Sphere((0.0, -101.5, 2.0), 100.0), Lambertian(0.8), None),
+             Prim(Sphere((-2.2, -0.2, 3.5), 1.0), Microfacet(0.9, alpha, alpha), None),
+             Prim(Sphere((2.2, -0.2, 3.5), 1.0), Specular(0.9), None)]
+    return prims, [0]
+
+
 def scan(prims, ray):
     """the loop shared by Scene::intersection / ray_hits_point / ray_hits_object (scene.rs:116-166):
     closest t > 0 in primitive order, strict `<`"""
@@ -425,11 +607,11 @@ def scan(prims, ray):
     return closest_t, closest
 
 
-# ------------------------------------------------------------------ integrator/hwss_naive.rs
-MAX_DEPTH, MIN_DEPTH = 15, 2
+# ------------------------------------------------------------------ integrator/hwss_naive.rs, integrator/swss_naive.rs
+MIN_DEPTH = 2   # MAX_DEPTH = 15 in both files; the S3 traces run the same loop to 32 (BASELINE config E)
 
 
-def direct_light(prims, lights, bsdf, hit, ray, smp):  # :95-157
+def direct_light(prims, lights, bsdf, hit, ray, wl, smp, hwss):  # hwss_naive.rs:95-157 / swss_naive.rs:92-153
     radiance = splat(0.0)
     shading_wo = world_to_shading(hit, -ray.d)
     light_idx = smp.gen_array_index(len(lights))                       # scene.rs:168-172
@@ -446,26 +628,26 @@ def direct_light(prims, lights, bsdf, hit, ray, smp):  # :95-157
         target_t = (light_pos - ray_to_light.o).len() / ray_to_light.d.len()
         if closest_t > target_t - F(0.001):
             shading_wi = world_to_shading(hit, ray_to_light.d)
-            bsdf_values, bsdf_pdfs = bsdf.evaluate(), bsdf.pdf(shading_wi)
-            cos_theta = abs(shading_wi.z)
-            mis_weight = balance_heuristic_2(splat(light_pdf), bsdf_pdfs)
-            radiance = add4(radiance, div4s(scale4(mul4(scale4(light_emission, mis_weight), bsdf_values), cos_theta), light_pdf))
+            bsdf_values, bsdf_pdfs = bsdf.evaluate(shading_wi, shading_wo, wl), bsdf.pdf(shading_wi, shading_wo)
+            cos_theta_ = abs(shading_wi.z)
+            mis_weight = balance_heuristic_2(splat(light_pdf), bsdf_pdfs) if hwss else light_pdf / (bsdf_pdfs[0] + light_pdf)
+            radiance = add4(radiance, div4s(scale4(mul4(scale4(light_emission, mis_weight), bsdf_values), cos_theta_), light_pdf))
     # sample BSDF
-    wi, bsdf_values, bsdf_pdfs = bsdf.sample(shading_wo, smp)
-    cos_theta = abs(wi.z)
+    wi, bsdf_values, bsdf_pdfs = bsdf.sample(shading_wo, wl, smp)
+    cos_theta_ = abs(wi.z)
     ray_to_light = Ray.spawn(hit.point, shading_to_world(hit, wi), hit.normal)
     if bsdf_pdfs[0] > ZERO:
         _, closest = scan(prims, ray_to_light)                         # scene.rs:151-166
         if closest is not None and closest[0] == light_prim_index:
             light_pdf = light_prim.sphere.pdf(hit, ray_to_light.d)
-            mis_weight = balance_heuristic_2(bsdf_pdfs, splat(light_pdf))
-            radiance = add4(radiance, div4s(scale4(mul4(scale4(light_emission, mis_weight), bsdf_values), cos_theta), bsdf_pdfs[0]))
+            mis_weight = balance_heuristic_2(bsdf_pdfs, splat(light_pdf)) if hwss else bsdf_pdfs[0] / (bsdf_pdfs[0] + light_pdf)
+            radiance = add4(radiance, div4s(scale4(mul4(scale4(light_emission, mis_weight), bsdf_values), cos_theta_), bsdf_pdfs[0]))
     return scale4(radiance, light_pick_weight)
 
 
-def radiance(prims, lights, ray, smp, trace):  # :28-93
+def radiance(prims, lights, ray, wl, smp, trace, hwss=True, max_depth=15):  # hwss_naive.rs:28-93 / swss_naive.rs:28-90
     rad, throughput, path_pdfs = splat(0.0), splat(1.0), splat(1.0)
-    for bounces in range(MAX_DEPTH):
+    for bounces in range(max_depth):
         closest_t, closest = scan(prims, ray)                          # scene.rs:116-132
         if closest is None:
             break
@@ -477,22 +659,26 @@ def radiance(prims, lights, ray, smp, trace):  # :28-93
         if bsdf is None:
             break
         if bounces == 0 and prim.light is not None:
-            rad = add4(rad, scale4(mul4(throughput, splat(prim.light)), balance_heuristic_1(path_pdfs)))
-        rad = add4(rad, mul4(throughput, direct_light(prims, lights, bsdf, hit, ray, smp)))
+            if hwss:
+                rad = add4(rad, scale4(mul4(throughput, splat(prim.light)), balance_heuristic_1(path_pdfs)))
+            else:
+                rad = add4(rad, mul4(throughput, splat(prim.light)))
+        rad = add4(rad, mul4(throughput, direct_light(prims, lights, bsdf, hit, ray, wl, smp, hwss)))
         shading_wo = world_to_shading(hit, -ray.d)
-        wi, bsdf_values, bsdf_pdfs = bsdf.sample(shading_wo, smp)
-        cos_theta = abs(wi.z)
-        if bsdf_pdfs[0] == ZERO or cos_theta == ZERO:
+        wi, bsdf_values, bsdf_pdfs = bsdf.sample(shading_wo, wl, smp)
+        cos_theta_ = abs(wi.z)
+        if bsdf_pdfs[0] == ZERO or cos_theta_ == ZERO:
             break
-        throughput = mul4(throughput, div4s(scale4(bsdf_values, cos_theta), bsdf_pdfs[0]))
-        path_pdfs = mul4(path_pdfs, bsdf_pdfs)
+        throughput = mul4(throughput, div4s(scale4(bsdf_values, cos_theta_), bsdf_pdfs[0]))
+        if hwss:
+            path_pdfs = mul4(path_pdfs, bsdf_pdfs)
         if bounces >= MIN_DEPTH:
             p = fmin(sum4(throughput), F(0.95))
             if smp.gen_0_1() > p:
                 break
             throughput = [t / p for t in throughput]
         ray = Ray.spawn(hit.point, shading_to_world(hit, wi), hit.normal)
-    return rad
+    return rad if hwss else [rad[0], ZERO, ZERO, ZERO]                 # swss_naive.rs:87
 
 
 # ------------------------------------------------------------------ spectrum/wavelength.rs, sample.rs, color.rs
@@ -540,24 +726,45 @@ def camera_sample(x, y, sample_index, width, height, seed, cam_pos, m):
     return smp, wl, Ray.new(origin, target - origin)
 
 
-def trace_sample(x, y, sample_index, width, height, seed, cam_pos, m, cmf, scene):
+def trace_sample(x, y, sample_index, width, height, seed, cam_pos, m, cmf, scene, hwss=True, max_depth=15):
     prims, lights = scene
     smp, wl, ray = camera_sample(x, y, sample_index, width, height, seed, cam_pos, m)
     tr = {"hit_prim": [], "hit_t": []}
-    rad = radiance(prims, lights, ray, smp, tr)
+    rad = radiance(prims, lights, ray, wl, smp, tr, hwss, max_depth)
     tr.update(hero=wl, ray_d=ray.d.tolist(), radiance=rad, xyz=to_xyz(rad, wl, cmf), draws=smp.draws)
     return tr
 
 
+def trace_set(xys, integrators, width, height, cam_pos, m, cmf, scene, max_depth, pad):
+    out = {k: [] for k in ("hero", "ray_d", "radiance", "xyz", "n_hits", "draws", "hit_prim", "hit_t")}
+    for (x, y, s), integ in zip(xys, integrators):
+        tr = trace_sample(int(x), int(y), int(s), width, height, 123456789, cam_pos, m, cmf, scene, hwss=(integ == 0), max_depth=max_depth)
+        out["hero"].append(tr["hero"]); out["ray_d"].append(tr["ray_d"]); out["radiance"].append(tr["radiance"]); out["xyz"].append(tr["xyz"])
+        out["n_hits"].append(len(tr["hit_prim"])); out["draws"].append(tr["draws"])
+        out["hit_prim"].append((tr["hit_prim"] + [-1] * pad)[:pad]); out["hit_t"].append((tr["hit_t"] + [ZERO] * pad)[:pad])
+    return out
+
+
+def save(name, xys, integrators, width, height, cam_pos, m, out, extra=None):
+    np.savez_compressed(os.path.join(HERE, name), xys=xys, width=np.uint32(width), height=np.uint32(height),
+                        cam_pos=np.array(cam_pos, np.float32), clip_to_world=np.array(m, np.float32),
+                        hero=np.array(out["hero"], np.float32), ray_d=np.array(out["ray_d"], np.float32),
+                        radiance=np.array(out["radiance"], np.float32), xyz=np.array(out["xyz"], np.float32),
+                        n_hits=np.array(out["n_hits"], np.uint32), draws=np.array(out["draws"], np.uint32),
+                        hit_prim=np.array(out["hit_prim"], np.int32), hit_t=np.array(out["hit_t"], np.float32), **(extra or {}))
+    print("wrote %s: %d samples, %d bounce records, mean radiance %.4f" %
+          (name, len(xys), int(np.sum(out["n_hits"])), float(np.mean(out["radiance"]))))
+
+
 def main():
     sys.path.insert(0, ROOT)
-    import iris_amd  # host-side camera only (iris_camera_new: camera.rs:10-21); no GPU, no oracle
+    import iris_amd  # host side only: the camera (iris_camera_new: camera.rs:10-21) and the GGX alpha (ggx.rs:66-73); no GPU, no oracle
     width = height = 512
     cam = iris_amd.Camera((0.0, 0.0, 0.0), F(width) / F(height))
     m = [[F(v) for v in row] for row in cam.clip_to_world]
     cam_pos = [F(v) for v in cam.position]
     cmf = load_cmf()
-    scene = default_scene()
+    # ---- the default scene, HwssNaive, depth 15
     rng = np.random.RandomState(20251111)
     xys = rng.randint(0, [width, height, 64], size=(256, 3)).astype(np.uint32)
     xys[16:, 1] = 230 + xys[16:, 1] % 282   # most of them below the horizon: spheres and ground, several bounces each
@@ -565,20 +772,30 @@ def main():
     xys[1] = (256, 300, 7)    # the middle sphere
     xys[2] = (30, 500, 63)    # the ground
     xys[3] = (5, 5, 1)        # the sky
-    out = {k: [] for k in ("hero", "ray_d", "radiance", "xyz", "n_hits", "draws", "hit_prim", "hit_t")}
-    for x, y, s in xys:
-        tr = trace_sample(int(x), int(y), int(s), width, height, 123456789, cam_pos, m, cmf, scene)
-        out["hero"].append(tr["hero"]); out["ray_d"].append(tr["ray_d"]); out["radiance"].append(tr["radiance"]); out["xyz"].append(tr["xyz"])
-        out["n_hits"].append(len(tr["hit_prim"])); out["draws"].append(tr["draws"])
-        out["hit_prim"].append((tr["hit_prim"] + [-1] * 16)[:16]); out["hit_t"].append((tr["hit_t"] + [ZERO] * 16)[:16])
-    np.savez_compressed(os.path.join(HERE, "traces_s1_restated.npz"), xys=xys, width=np.uint32(width), height=np.uint32(height),
-                        cam_pos=np.array(cam_pos, np.float32), clip_to_world=np.array(m, np.float32),
-                        hero=np.array(out["hero"], np.float32), ray_d=np.array(out["ray_d"], np.float32),
-                        radiance=np.array(out["radiance"], np.float32), xyz=np.array(out["xyz"], np.float32),
-                        n_hits=np.array(out["n_hits"], np.uint32), draws=np.array(out["draws"], np.uint32),
-                        hit_prim=np.array(out["hit_prim"], np.int32), hit_t=np.array(out["hit_t"], np.float32))
-    print("wrote traces_s1_restated.npz: %d samples, %d bounce records, mean radiance %.4f" %
-          (len(xys), int(np.sum(out["n_hits"])), float(np.mean(out["radiance"]))))
+    out = trace_set(xys, [0] * len(xys), width, height, cam_pos, m, cmf, default_scene(), 15, 16)
+    save("traces_s1_restated.npz", xys, [0] * len(xys), width, height, cam_pos, m, out)
+    # ---- the glossy/dielectric scene, depth 32: 192 samples through HwssNaive, 96 through SwssNaive; two thirds of them aimed at the
+    # three non-Lambertian spheres (rows 230-330 of the 512-row film, columns around 256 and 256 -+ 115)
+    import ctypes
+    alpha = F(iris_amd.ffi.load().iris_roughness_to_alpha(ctypes.c_float(0.2)))
+    rng = np.random.RandomState(20261111)
+    n3 = 288
+    xys3 = rng.randint(0, [width, height, 256], size=(n3, 3)).astype(np.uint32)
+    for i in range(n3):
+        if i % 3 != 2:
+            cx = (256, 141, 371)[i % 3 if i % 6 < 3 else (i + 1) % 3]
+            xys3[i, 0] = np.clip(cx + rng.randint(-45, 46), 0, width - 1)
+            xys3[i, 1] = 235 + rng.randint(0, 95)
+        else:
+            xys3[i, 1] = 230 + xys3[i, 1] % 282
+    integ3 = np.array([0] * 192 + [2] * 96, np.uint32)   # enum iris_integrator: 0 HwssNaive, 2 SwssNaive
+    out3 = trace_set(xys3, integ3, width, height, cam_pos, m, cmf, glossy_dielectric_scene(alpha), 32, 32)
+    save("traces_s3_restated.npz", xys3, integ3, width, height, cam_pos, m, out3, extra={"integrator": integ3, "alpha": np.float32(alpha), "max_depth": np.uint32(32)})
+    kinds = {}
+    for row, n in zip(out3["hit_prim"], out3["n_hits"]):
+        for p_ in row[:n]:
+            kinds[p_] = kinds.get(p_, 0) + 1
+    print("S3 bounce records by primitive (0 light, 1 dielectric, 2 ground, 3 GGX, 4 mirror):", dict(sorted(kinds.items())))
 
 
 if __name__ == "__main__":

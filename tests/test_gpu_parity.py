@@ -226,6 +226,27 @@ def test_traces_match_the_independent_numpy_restatement(gpu):
             assert np.array_equal(bits(list(val)), bits(g[name][i])), (name, i)
 
 
+def test_traces_match_the_independent_restatement_of_the_glossy_dielectric_scene(gpu):
+    """The GPU against tests/golden/traces_s3_restated.npz: GGX, mirror and dispersive dielectric at depth 32, HwssNaive and
+    SwssNaive, computed in numpy float32 from the Rust text (tests/golden/restate_path.py) -- no C code produced these numbers."""
+    from iris_amd import Camera, Render, Scene
+    g = np.load(os.path.join(GOLD, "traces_s3_restated.npz"))
+    scene = Scene.glossy_dielectric()
+    gpu.upload(scene)
+    w, h = int(g["width"]), int(g["height"])
+    for integ in (0, 2):
+        sel = np.flatnonzero(g["integrator"] == integ)
+        r = Render(w, h, 256, scene, integrator=integ, max_depth=int(g["max_depth"]), camera=Camera([float(v) for v in g["cam_pos"]], np.float32(w) / np.float32(h)))
+        got = gpu.dbg_trace(r, g["xys"][sel])
+        for i, t in zip(sel, got):
+            n = int(g["n_hits"][i])
+            assert t.n_hits == n and t.draws == int(g["draws"][i]), i
+            assert list(t.hit_prim[:n]) == list(g["hit_prim"][i][:n])
+            assert np.array_equal(bits(list(t.hit_t[:n])), bits(g["hit_t"][i][:n]))
+            for name, val in (("hero", t.hero), ("ray_d", t.ray_d), ("radiance", t.radiance), ("xyz", t.xyz)):
+                assert np.array_equal(bits(list(val)), bits(g[name][i])), (name, i)
+
+
 def oracle_film(O, flat, w, h, spp, **kw):
     osc = O.OracleScene(flat)
     cam = O.camera_new([0, 0, 0], np.float32(w) / np.float32(h))
@@ -351,13 +372,27 @@ def test_film_vs_libm_trig_oracle(gpu, libm_trig):
     assert off.any(axis=2).mean() < 0.02
 
 
-def image_gate(gpu, O, scene, w, h, spp, max_depth, n_parts=32, ref_parts=16):
+def gate_stats(film, parts, ref, se_ref):
+    """(rel_mse, fraction of |z| > 3, mean z^2, mean min(z^2, 16), median z^2) of a film (the mean of its `parts`) against a reference"""
+    n_parts = len(parts)
+    rel_mse = float(np.sum((film - ref) ** 2) / np.sum(ref ** 2))
+    se_film = parts.std(axis=0, ddof=1) / np.sqrt(n_parts)
+    se = np.sqrt(se_film ** 2 + se_ref ** 2)
+    lit = se > 0
+    assert lit.mean() > 0.3
+    z2 = ((film - ref)[lit] / se[lit]) ** 2
+    return rel_mse, float(np.mean(z2 > 9.0)), float(np.mean(z2)), float(np.mean(np.minimum(z2, 16.0))), float(np.median(z2))
+
+
+def image_gate(gpu, O, scene, w, h, spp, max_depth, n_parts=32, ref_parts=16, null_draws=0):
     """north_star's image gate: the GPU film at `spp` against the CPU oracle (libm sin/cos, what the
     reference calls) at 16x spp over DISJOINT sample indices [spp, 17 spp), so the two are independent estimates.
     (1) relative MSE over all three XYZ channels;
     (2) per pixel and channel z = (gpu - ref) / sqrt(se_gpu^2 + se_ref^2), both standard errors estimated from disjoint
         sample-range parts of the respective render (32 GPU parts, 16 oracle parts of `spp` samples each).
-    Returns (rel_mse, fraction of |z| > 3, mean z^2, mean min(z^2, 16), median z^2)."""
+    Returns (rel_mse, fraction of |z| > 3, mean z^2, mean min(z^2, 16), median z^2), and with null_draws > 0 the same five numbers
+    for that many UNBIASED films: CPU-oracle renders of further disjoint sample ranges [(17 + k) spp, (18 + k) spp), each in the
+    same 32 parts, against the same reference -- draws from the distribution the GPU's statistics have if the GPU is right."""
     from iris_amd import Render
     flat = gpu.upload(scene)
     r = Render(w, h, spp, scene, max_depth=max_depth)
@@ -368,39 +403,53 @@ def image_gate(gpu, O, scene, w, h, spp, max_depth, n_parts=32, ref_parts=16):
                        for k in range(ref_parts)])
     ref = rparts.mean(axis=0)
     se_ref = rparts.std(axis=0, ddof=1) / np.sqrt(ref_parts)
-    rel_mse = float(np.sum((film - ref) ** 2) / np.sum(ref ** 2))
     per = spp // n_parts
     parts = np.stack([gpu.render_film(r, spp_begin=k * per, spp_count=per).astype(np.float64) * n_parts for k in range(n_parts)])
-    se_gpu = parts.std(axis=0, ddof=1) / np.sqrt(n_parts)
-    se = np.sqrt(se_gpu ** 2 + se_ref ** 2)
-    lit = se > 0
-    assert lit.mean() > 0.3
-    z2 = ((film - ref)[lit] / se[lit]) ** 2
-    return rel_mse, float(np.mean(z2 > 9.0)), float(np.mean(z2)), float(np.mean(np.minimum(z2, 16.0))), float(np.median(z2))
+    stats = gate_stats(film, parts, ref, se_ref)
+    if not null_draws:
+        return stats
+    total = spp * (1 + ref_parts + null_draws)  # spp_total of the null renders: each part is scaled by total / per to a film of its own
+    null = []
+    for d in range(null_draws):
+        begin = spp * (1 + ref_parts + d)
+        nparts = np.stack([osc.render(cam, O.make_params(w, h, total, spp_begin=begin + k * per, spp_count=per, max_depth=max_depth), nthreads=16)[0].astype(np.float64)
+                           * (total / per) for k in range(n_parts)])
+        null.append(gate_stats(nparts.mean(axis=0), nparts, ref, se_ref))
+    return stats, np.array(null)
 
 
 @pytest.mark.parametrize("scene_name,w,h,spp,max_depth", [("s1", 48, 48, 1024, 15), ("s3", 40, 40, 2048, 32), ("s3env", 40, 40, 2048, 32)])
 def test_converged_image_tolerance(gpu, libm_trig, scene_name, w, h, spp, max_depth):
     """The image gate on the default scene, on the glossy/dielectric scene at depth 32 and on the same under the HDR sky:
     relative MSE < 1e-3 (all three channels), fewer than 1 % of the z values beyond 3 sigma (0.27 % expected) and mean z^2
-    in [0.8, 1.25] -- a bias of one standard error would add 1 to mean z^2.  Two documented departures, both measured on
-    unbiased renders (the GPU film equals the oracle's bit for bit under the specified sin/cos):
+    in [0.8, 1.25] -- a bias of one standard error would add 1 to mean z^2.  Two documented departures:
     * S3 without the sky is heavy-tailed (rare bright dispersion/caustic paths dominate ~2 % of the pixel-channels, whose
-      2048-sample means are far from normal and whose variance estimates miss the tail): measured 1.7 % beyond 3, mean z^2 1.34,
-      median z^2 0.54 (chi^2_1: 0.455).  Its bounds are 3 %, a clipped mean (z^2 capped at 16) below 1.6 and median below 0.8;
-      a one-sigma bias would put the clipped mean above 2 and the median above 1.
+      2048-sample means are far from normal and whose variance estimates miss the tail), so its z statistics do not follow the
+      normal-theory values and fixed bounds would have to be set from a measurement.  Instead their bounds come from the null
+      distribution itself, with a STATED FALSE-POSITIVE BUDGET: 200 unbiased films (CPU-oracle renders of 200 further disjoint
+      sample ranges, same parts, same reference) give 200 draws of each statistic; the GPU film must not exceed the second
+      largest of them in the fraction beyond 3 sigma, in the clipped mean z^2 and in the median z^2 (each a 1 % one-sided test
+      under the null: 3 % in all by the union bound), and a film biased by half a standard error fails (checked below on the null
+      draws themselves: shifting one of them by 0.5 se puts its clipped mean z^2 above every unshifted draw).
     * Under the sky the Owen-scrambled Sobol points beat independent ones (mean z^2 0.72): the lower bound is 0.5."""
     from iris_amd import EnvMap, Scene, UpsampleTable
     scene = {"s1": Scene.dummy, "s3": Scene.glossy_dielectric, "s3env": Scene.glossy_dielectric}[scene_name]()
     if scene_name == "s3env":
         scene.env_map = EnvMap.sky(UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff")), 64, 64)
+    if scene_name == "s3":
+        (rel_mse, beyond3, z2, z2_clipped, z2_median), null = image_gate(gpu, libm_trig, scene, w, h, spp, max_depth, null_draws=200)
+        bound = np.sort(null, axis=0)[-2]  # the second largest of 200 draws: exceeded by an unbiased film with probability ~1 %
+        print("image gate s3: rel_mse %.3g, |z|>3: %.4f (null 99%%: %.4f), mean z^2 %.3f, clipped %.3f (null median %.3f, 99%%: %.3f), median z^2 %.3f (null 99%%: %.3f)"
+              % (rel_mse, beyond3, bound[1], z2, z2_clipped, float(np.median(null[:, 3])), bound[3], z2_median, bound[4]))
+        assert rel_mse < 1e-3
+        assert beyond3 <= bound[1] and z2_clipped <= bound[3] and z2_median <= bound[4]
+        # power of the gate: half a standard error of bias adds 0.25 to every z^2 on average, which must leave the null's range
+        assert float(np.median(null[:, 3])) + 0.25 > bound[3]
+        return
     rel_mse, beyond3, z2, z2_clipped, z2_median = image_gate(gpu, libm_trig, scene, w, h, spp, max_depth)
     print("image gate %s: rel_mse %.3g, |z|>3: %.4f, mean z^2 %.3f (clipped %.3f), median z^2 %.3f" % (scene_name, rel_mse, beyond3, z2, z2_clipped, z2_median))
     assert rel_mse < 1e-3
-    if scene_name == "s3":
-        assert beyond3 < 0.03 and 0.5 < z2_clipped < 1.6 and z2_median < 0.8
-    else:
-        assert beyond3 < 0.01 and (0.8 if scene_name == "s1" else 0.5) < z2 < 1.25
+    assert beyond3 < 0.01 and (0.8 if scene_name == "s1" else 0.5) < z2 < 1.25
 
 
 # ---- BASELINE sizes: size-independent properties -----------------------------------------------------

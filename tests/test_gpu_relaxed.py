@@ -87,10 +87,40 @@ def test_relaxed_build_passes_the_image_gate(relaxed, libm_trig, scene_name, w, 
     scene = {"s1": Scene.dummy, "s3": Scene.glossy_dielectric, "s3env": Scene.glossy_dielectric}[scene_name]()
     if scene_name == "s3env":
         scene.env_map = EnvMap.sky(UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff")), 64, 64)
+    if scene_name == "s3":  # bounds from the null distribution, 1 % false positives per statistic (test_converged_image_tolerance)
+        (rel_mse, beyond3, z2, z2_clipped, z2_median), null = image_gate(relaxed, libm_trig, scene, w, h, spp, max_depth, null_draws=200)
+        bound = np.sort(null, axis=0)[-2]
+        print("image gate (relaxed) s3: rel_mse %.3g, |z|>3: %.4f (<= %.4f), clipped mean z^2 %.3f (<= %.3f), median z^2 %.3f (<= %.3f)"
+              % (rel_mse, beyond3, bound[1], z2_clipped, bound[3], z2_median, bound[4]))
+        assert rel_mse < 1e-3 and beyond3 <= bound[1] and z2_clipped <= bound[3] and z2_median <= bound[4]
+        return
     rel_mse, beyond3, z2, z2_clipped, z2_median = image_gate(relaxed, libm_trig, scene, w, h, spp, max_depth)
     print("image gate (relaxed) %s: rel_mse %.3g, |z|>3: %.4f, mean z^2 %.3f (clipped %.3f), median z^2 %.3f" % (scene_name, rel_mse, beyond3, z2, z2_clipped, z2_median))
     assert rel_mse < 1e-3
-    if scene_name == "s3":
-        assert beyond3 < 0.03 and 0.5 < z2_clipped < 1.6 and z2_median < 0.8
-    else:
-        assert beyond3 < 0.01 and (0.8 if scene_name == "s1" else 0.5) < z2 < 1.25
+    assert beyond3 < 0.01 and (0.8 if scene_name == "s1" else 0.5) < z2 < 1.25
+
+
+@pytest.mark.parametrize("scene_name,max_depth", [("s3", 32), ("s3env", 32)])
+def test_relaxed_arithmetic_adds_no_bias_at_equal_samples(gpu, relaxed, scene_name, max_depth):
+    """The direct check the z statistics cannot give (ADVICE, round 2): exact and relaxed builds render the SAME samples, so their
+    per-pixel difference carries no Monte-Carlo noise of its own, only the effect of the 1-ulp reciprocals / roots / sin / cos and of
+    the paths those flip.  Over 16 disjoint sample-range parts the mean signed relative difference of the film's luminance (Y) is
+    tested against its standard error (|mean| < 4 se: false-positive rate 6e-5) and must be small in absolute terms (< 2e-4 of the
+    film's mean): a systematic shift of the relaxed arithmetic would show here long before it showed in the image gate."""
+    from iris_amd import EnvMap, Render, Scene, UpsampleTable
+    scene = Scene.glossy_dielectric()
+    if scene_name == "s3env":
+        scene.env_map = EnvMap.sky(UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff")), 64, 64)
+    gpu.upload(scene)
+    relaxed.upload(scene)
+    n_parts, per = 16, 64
+    r = Render(96, 72, n_parts * per, scene, max_depth=max_depth)
+    rel = []
+    for k in range(n_parts):
+        a = gpu.render_film(r, spp_begin=k * per, spp_count=per).astype(np.float64)[..., 1]
+        b = relaxed.render_film(r, spp_begin=k * per, spp_count=per).astype(np.float64)[..., 1]
+        rel.append((b.sum() - a.sum()) / a.sum())
+    rel = np.array(rel)
+    mean, se = rel.mean(), rel.std(ddof=1) / np.sqrt(n_parts)
+    print("relaxed - exact, %s, equal samples: mean relative difference of Y %.3g +- %.3g (se)" % (scene_name, mean, se))
+    assert abs(mean) < 4.0 * se + 1e-7 and abs(mean) < 2e-4

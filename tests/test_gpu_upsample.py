@@ -52,6 +52,31 @@ def test_batch_equals_the_host_lookup_bit_for_bit(gpu, max_hdr):
             assert np.array_equal(bits(list(s.coefficients) + [s.hdr_coefficient]), bits(tex[k]))
 
 
+def test_batch_equals_the_oracle_lookup_directly(gpu, oracle):
+    """One hop, not two: the GPU batch against the ORACLE's get_spectrum_hdr / get_spectrum (oracle/iris_oracle.c's restatement of
+    upsample.rs:46-106, on its own copy of the table), bit for bit -- 20 000 HDR, grey, tied and tiny values with the reference's
+    clamp at 50, and LDR values through get_spectrum."""
+    from iris_amd import UpsampleTable
+    from test_upsample import TABLE, oracle_lookup
+    table = UpsampleTable(TABLE)
+    o = oracle.lib().orc_upsample_table_load(TABLE.encode())
+    assert o
+    try:
+        gpu.upload_upsample_table(table)
+        rgb = rgb_cases(np.random.RandomState(4321), 20000)
+        tex, _ = gpu.get_spectrum_hdr_batch(rgb, max_hdr=50.0)
+        for k in range(len(rgb)):
+            c, h = oracle_lookup(oracle, o, rgb[k], hdr=True)
+            assert np.array_equal(bits(tex[k]), bits(list(c) + [h])), (k, rgb[k])
+        ldr = np.random.RandomState(99).uniform(0.0, 1.0, size=(4000, 3)).astype(np.float32)
+        tex, _ = gpu.get_spectrum_hdr_batch(ldr)
+        for k in range(len(ldr)):
+            c, _ = oracle_lookup(oracle, o, ldr[k])
+            assert np.array_equal(bits(tex[k, :3]), bits(c)) and tex[k, 3] == 1.0, (k, ldr[k])
+    finally:
+        oracle.lib().orc_upsample_table_free(o)
+
+
 def test_batch_on_ldr_values_is_get_spectrum(gpu):
     """For RGB values in [0, 1] the HDR factor is 1 and the division by it exact, so the batch also serves as the device form of
     UpsampleTable::get_spectrum (upsample.rs:59-106): same three coefficients bit for bit, factor exactly 1."""

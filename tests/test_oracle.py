@@ -309,3 +309,35 @@ def test_oracle_matches_the_independent_numpy_restatement(oracle):
         assert n_bounces > 150 and float(g["radiance"].max()) > 0.5  # not a set of sky pixels (the light seen directly: 3.0 x balance_heuristic_1 = 0.75)
     finally:
         oracle.set_trig_mode(oracle.TRIG_LIBM)
+
+
+
+def test_oracle_matches_the_independent_restatement_of_the_glossy_dielectric_scene(oracle):
+    """tests/golden/traces_s3_restated.npz (tests/golden/restate_path.py): whole camera samples on the glossy/dielectric scene at
+    depth 32 -- GGX microfacet (ggx.rs, microfacet.rs), mirror (specular.rs), dispersive dielectric (fresnel.rs, math/mod.rs:35-72) --
+    192 through HwssNaive and 96 through SwssNaive (swss_naive.rs), restated in numpy float32 from the Rust text without any code of
+    the oracle's.  Bit for bit: wavelengths, primary ray, primitive and t of every hit, draw count, radiance, XYZ."""
+    g = np.load(os.path.join(GOLD, "traces_s3_restated.npz"))
+    from iris_amd import Scene
+    oracle.set_trig_mode(oracle.TRIG_IRIS)
+    try:
+        w, h = int(g["width"]), int(g["height"])
+        cam = oracle.camera_new([float(v) for v in g["cam_pos"]], np.float32(w) / np.float32(h))
+        flat = Scene.glossy_dielectric().flatten()
+        assert [np.float32(b[3]) for b in flat.bsdfs if int(b[0]) == 1] == [g["alpha"]]  # the GGX alpha the traces were made with
+        sc = oracle.OracleScene(flat)
+        kinds = set()
+        for i, (x, y, s) in enumerate(g["xys"]):
+            p = oracle.make_params(w, h, 256, integrator=int(g["integrator"][i]), max_depth=int(g["max_depth"]))
+            t = sc.trace(cam, p, int(x), int(y), int(s))
+            n = int(g["n_hits"][i])
+            assert t.n_hits == n and t.draws == int(g["draws"][i]), (i, x, y, s)
+            assert list(t.hit_prim[:n]) == list(g["hit_prim"][i][:n])
+            kinds.update(g["hit_prim"][i][:n].tolist())
+            for name, got in (("hero", t.hero), ("ray_d", t.ray_d), ("radiance", t.radiance), ("xyz", t.xyz)):
+                assert np.array_equal(np.array(list(got), np.float32).view(np.uint32), g[name][i].view(np.uint32)), (name, i)
+            assert np.array_equal(np.array(list(t.hit_t[:n]), np.float32).view(np.uint32), g["hit_t"][i][:n].view(np.uint32)), i
+        assert kinds == {0, 1, 2, 3, 4}  # every primitive, so every BSDF kind, was hit
+        assert int(np.sum(g["n_hits"])) > 500 and np.any(g["radiance"][:192, 1:] != g["radiance"][:192, :1])  # dispersion: the wavelengths differ
+    finally:
+        oracle.set_trig_mode(oracle.TRIG_LIBM)
