@@ -93,6 +93,7 @@ extern "C" {
     pub fn iris_sample_range(spp_count: u32, part: u32, n_parts: u32, begin: *mut u32, count: *mut u32) -> c_int;
     pub fn iris_film_to_rgb(xyz: *const f32, n_pixels: usize, rgb: *mut f32) -> c_int;
     pub fn iris_get_stats(ctx: *const iris_ctx, out: *mut iris_stats) -> c_int;
+    pub fn iris_get_invariant_counts(ctx: *const iris_ctx, out: *mut u64) -> c_int;
     // ---- stage-level entry points for parity tests
     pub fn iris_dbg_sampler(ctx: *mut iris_ctx, n: u32, xys: *const u32, seed: u32, ndraws: u32, out: *mut f32) -> c_int;
     pub fn iris_dbg_raygen(ctx: *mut iris_ctx, camera: *const iris_camera, params: *const iris_render_params, n: u32, xys: *const u32, hero: *mut f32, ray_o: *mut f32, ray_d: *mut f32) -> c_int;

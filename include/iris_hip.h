@@ -332,6 +332,17 @@ int iris_film_to_rgb(const float *xyz, size_t n_pixels, float *rgb);
 
 int iris_get_stats(const iris_ctx *ctx, iris_stats *out);
 
+/* Where the reference's DEBUG build would have panicked during the last iris_render* call: its debug_assert!s on the hot path
+ * -- Vec3 components finite (math/vec3.rs:24-31), SpectralSample and PdfSet components non-negative and not NaN
+ * (spectrum/sample.rs:64-73, math/pdf.rs:49-58), the cone-sampled light point within 2 % of its sphere (shape/sphere.rs:131-132) --
+ * evaluated at a fixed list of check points per shaded bounce (the hit's frame and the next ray; the path's radiance after the
+ * bounce's light and its throughput after the update; the sampled continuation's pdfs and the path pdfs; the light point) and
+ * COUNTED instead of trapping: out[0] Vec3, out[1] SpectralSample, out[2] PdfSet, out[3] light point.  The oracle counts at the
+ * same points (orc_invariant_counts), so the totals are comparable.  Only libiris_hip_debug.so (the same sources built with
+ * -DIRIS_DEBUG_INVARIANTS=1: the checks cost registers, and that build runs the kernels that shade without deferring their
+ * visibility queries) counts them; every other build returns IRIS_E_STATE and zeros. */
+int iris_get_invariant_counts(const iris_ctx *ctx, uint64_t out[4]);
+
 /* ---- stage-level entry points for parity tests ------------------------ */
 /* xys: n triplets (x, y, sample_index). */
 

@@ -19,6 +19,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libiris_hip.so")
 # The opt-in relaxed-arithmetic build of the same sources (-DIRIS_RELAXED=1, iris_device.h): never the default, never what the
 # parity tests load; Context(relaxed=True) / bench.py's `relaxed` leg select it.
 LIB_RELAXED_PATH = os.path.join(LIB_DIR, "libiris_hip_relaxed.so")
+# The debug-invariants build (-DIRIS_DEBUG_INVARIANTS=1, iris_device.h): counts, at fixed check points, where the reference's debug
+# build would have panicked; Context(debug=True) selects it, tests/test_gpu_invariants.py compares with the oracle.
+LIB_DEBUG_PATH = os.path.join(LIB_DIR, "libiris_hip_debug.so")
 SOURCES = [os.path.join(CSRC, "iris_kernels.hip"), os.path.join(CSRC, "iris_host.cpp"), os.path.join(CSRC, "iris_bvh_build.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "iris_device.h"), os.path.join(CSRC, "iris_exact.h"), os.path.join(CSRC, "iris_bvh_build.h"), os.path.join(CSRC, "tables", "cie_cmf.inc"),
                   os.path.join(CSRC, "tables", "sobol_rev16.inc"), os.path.join(HERE, "..", "include", "iris_hip.h")]
@@ -41,6 +44,8 @@ def build(force=False, extra=()):
         jobs.append(subprocess.Popen([HIPCC] + FLAGS + list(extra) + ["-o", LIB_PATH] + SOURCES))
     if force or needs_build(LIB_RELAXED_PATH):
         jobs.append(subprocess.Popen([HIPCC] + FLAGS + ["-DIRIS_RELAXED=1"] + list(extra) + ["-o", LIB_RELAXED_PATH] + SOURCES))
+    if force or needs_build(LIB_DEBUG_PATH):
+        jobs.append(subprocess.Popen([HIPCC] + FLAGS + ["-DIRIS_DEBUG_INVARIANTS=1"] + list(extra) + ["-o", LIB_DEBUG_PATH] + SOURCES))
     codes = [j.wait() for j in jobs]
     if any(codes):
         raise subprocess.CalledProcessError(max(codes), HIPCC)

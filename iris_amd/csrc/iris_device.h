@@ -1356,7 +1356,7 @@ IRIS_DEV void scan_closest(const SceneDev &sc, const SphereStage &st, bool activ
 
 IRIS_RADIOMETRIC_BEGIN
 // ---------------------------------------------------------------- sphere light (shape/sphere.rs:77-162)
-IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &smp, V3 &p_out, float &pdf_out, bool pin = true) {
+IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &smp, V3 &p_out, float &pdf_out, bool pin = true, bool *off_sphere = nullptr) {
     float u0 = gen_0_1(ring, smp);
     float u1 = gen_0_1(ring, smp);
     V3 position = v3(sp.x, sp.y, sp.z);
@@ -1395,6 +1395,12 @@ IRIS_DEV void sphere_sample(float4 sp, const Hit &hit, DrawRing ring, Sampler &s
     V3 normal = ((sin_alpha * cphi) * (-wc_x) + (sin_alpha * sphi) * (-wc_y)) + cos_alpha * (-wc);
     V3 sampled_point_local = radius * normalize(normal);
     p_out = position + sampled_point_local;
+#if IRIS_DEBUG_INVARIANTS
+    if (off_sphere) {  // sphere.rs:131-132
+        const float dist = __builtin_sqrtf(distance_squared(p_out, position));
+        *off_sphere = !(dist >= radius * 0.98f) || !(dist <= radius * 1.02f);
+    }
+#endif
     pdf_out = pdf_cone(cos_theta_max);
 }
 IRIS_DEV float sphere_pdf(float4 sp, const Hit &hit, V3 wi, unsigned long long &sphere_tests) {
@@ -1627,7 +1633,29 @@ IRIS_DEV V3 env_sample(const SceneDev &sc, float u0, float u1) {
 
 IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- path state and the two stages' per-lane work
-struct Counters { uint32_t samples, bounces, rays; unsigned long long sphere_tests; };
+// -DIRIS_DEBUG_INVARIANTS=1 (libiris_hip_debug.so): the debug_assert!s of the reference's hot path, counted instead of trapping, at a
+// fixed list of check points per shaded bounce -- the list oracle/iris_oracle.c counts too, so the totals are comparable:
+//   inv[0] Vec3 not finite (vec3.rs:24-31): the hit's frame; the next ray           inv[1] SpectralSample negative or NaN (sample.rs:64-73):
+//   radiance after the bounce's light, throughput after its update   inv[2] PdfSet negative or NaN (pdf.rs:49-58): the sampled
+//   continuation's pdfs, the path pdfs after the update (HWSS)       inv[3] cone-sampled light point off its sphere by > 2 % (sphere.rs:131-132)
+#ifndef IRIS_DEBUG_INVARIANTS
+#define IRIS_DEBUG_INVARIANTS 0
+#endif
+struct Counters {
+    uint32_t samples, bounces, rays;
+    unsigned long long sphere_tests;
+#if IRIS_DEBUG_INVARIANTS
+    uint32_t inv[4];
+#endif
+};
+#if IRIS_DEBUG_INVARIANTS
+#define IRIS_INV(cnt, k, cond) do { if (cond) (cnt).inv[k]++; } while (0)
+#else
+#define IRIS_INV(cnt, k, cond) do { } while (0)
+#endif
+
+IRIS_DEV bool v3_bad(V3 a) { return !(__builtin_isfinite(a.x) && __builtin_isfinite(a.y) && __builtin_isfinite(a.z)); }
+IRIS_DEV bool f4_bad(F4 a) { return !(a.v[0] >= 0.0f && a.v[1] >= 0.0f && a.v[2] >= 0.0f && a.v[3] >= 0.0f); }
 
 struct PathState {
     Ray ray;
@@ -1771,6 +1799,8 @@ template <int INTEG, int CLS, int DEFER = 0>
 IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const FrameDev &fr, SobolLds tab, DrawRing ring, bool active,
                            PathState &ps, int prim, float t, Counters &cnt, Deferred *df = nullptr) {
     static_assert(!DEFER || CLS == IRIS_CLS_LAMBERT_CONSTANT, "the deferred form keeps one value for the four wavelengths");
+    // (IRIS_DEBUG_INVARIANTS: the counters check the radiance where the bounce's light has been added, so the debug build launches
+    // no deferring kernel -- PoolGeom::ON and use_queue_kernels are off there)
     if (DEFER && active) { df->pending = false; df->want1 = false; df->has2 = false;  // (lanes that wait for their rays keep what they deferred)
         df->limit1 = __builtin_inff(); df->c1 = 0.0f; df->c2 = 0.0f; df->thr = 0.0f; df->weight = 0.0f;
         if (DEFER == 2) { df->limit2 = __builtin_inff(); df->tie2 = 0x7fffffff; df->spec_tests2 = 0u; } }
@@ -1853,7 +1883,13 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             } else {
                 light_emission = spectrum_evaluate(light_spectrum(sc, light_idx, light_prim), wl, MONO);
                 light_sphere = sc.light_rec[3u * light_idx];
+#if IRIS_DEBUG_INVARIANTS
+                bool off_sphere = false;
+                sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf, TRIG_PIN, &off_sphere);
+                IRIS_INV(cnt, 3, off_sphere);
+#else
                 sphere_sample(light_sphere, hit, ring, ps.smp, light_pos, light_pdf, TRIG_PIN);
+#endif
                 shadow1 = ray_spawn_to(hit.point, light_pos, hit.normal);
                 facing_forward = dot(light_pos - hit.point, hit.normal) > 0.0f;
                 want1 = light_pdf > 0.0f && facing_forward != hit.back_face && distance_squared(light_pos, hit.point) > 0.00001f;
@@ -1979,16 +2015,21 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
     }
 
     if (alive) {
+        IRIS_INV(cnt, 0, v3_bad(hit.point) || v3_bad(hit.normal) || v3_bad(hit.tangeant) || v3_bad(hit.bitangeant));
+        IRIS_INV(cnt, 1, f4_bad(ps.rad));
         // hwss_naive.rs:64-88
         V3 wi;
         F4 bsdf_values, bsdf_pdfs;
         bsdf_sample(sc, bsdf, shading_wo, wl, ring, ps.smp, MONO, wi, bsdf_values, bsdf_pdfs, TRIG_PIN);
+        IRIS_INV(cnt, 2, f4_bad(bsdf_pdfs));
         float cos_t = fabs_(cos_theta(wi));
         if (hero(bsdf_pdfs) == 0.0f || cos_t == 0.0f) {
             alive = false;
         } else {
             ps.thr = ps.thr * div4(bsdf_values * cos_t, hero(bsdf_pdfs), MONO);
             if (HWSS) ps.ppdf = ps.ppdf * bsdf_pdfs;
+            IRIS_INV(cnt, 1, f4_bad(ps.thr));
+            IRIS_INV(cnt, 2, HWSS && f4_bad(ps.ppdf));
             if (ps.bounce >= fr.min_depth) {
                 float p = rmin(sum(ps.thr), 0.95f);
                 if (gen_0_1(ring, ps.smp) > p) alive = false;
@@ -1996,6 +2037,7 @@ IRIS_DEV bool shade_bounce(const SceneDev &sc, const SphereStage &st, const Fram
             }
             if (alive) {
                 ps.ray = ray_spawn(hit.point, shading_to_world(hit, wi), hit.normal);
+                IRIS_INV(cnt, 0, v3_bad(ps.ray.o) || v3_bad(ps.ray.d));
                 ps.bounce += 1u;
                 if (ps.bounce >= fr.max_depth) alive = false;  // for bounces in 0..MAX_DEPTH
             }

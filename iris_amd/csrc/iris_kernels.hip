@@ -37,6 +37,7 @@ using namespace iris;
 namespace {
 
 constexpr int BLOCK = 256;
+#define IRIS_N_COUNTERS 24  // work counters 0-3, phase timers 4-9 and 11-16 (diagnostic build), sky samples 10, invariant counters 20-23 (debug build)
 static_assert(BLOCK == IRIS_BLOCK, "the draw ring stride is the workgroup size");
 constexpr uint32_t STATE_ALIVE = 0x80000000u;
 
@@ -147,6 +148,14 @@ __device__ __forceinline__ void flush_counters(unsigned long long *counters, con
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         if (lane_id() == 0u && x) atomicAdd(&counters[k], x);
     }
+#if IRIS_DEBUG_INVARIANTS
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned long long x = c.inv[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane_id() == 0u && x) atomicAdd(&counters[20 + k], x);
+    }
+#endif
 }
 __device__ __forceinline__ void flush_counters(const WfArgs &a, const Counters &c) { flush_counters(a.counters, c); }
 
@@ -358,7 +367,7 @@ template <int CLS, bool BVH> struct PqGeom {  // < CAP - 63 queued when a genera
 // POOLED (hierarchy + Lambertian/constant class: the 10k-sphere configuration): the extension rays and the light-sample visibility
 // queries of a wave are traversed together by bvh_pooled, detached from the lanes that own them (iris_device.h); the shade phase
 // leaves its visibility query to the next loop top (shade_bounce<.., DEFER>), where the paths that ended wait for it as LANE_FIN.
-template <int CLS, bool BVH> struct PoolGeom { static constexpr bool ON = BVH && CLS == IRIS_CLS_LAMBERT_CONSTANT; };
+template <int CLS, bool BVH> struct PoolGeom { static constexpr bool ON = BVH && CLS == IRIS_CLS_LAMBERT_CONSTANT && !IRIS_DEBUG_INVARIANTS; };  // (the debug build defers nothing)
 // Three waves per SIMD (168 VGPR) for every class: the general classes would fit 181-189 VGPR without their 28-44 B of scratch at
 // two waves, and lose more to the missing wave than the spills cost (S3 225 -> 279 ms, config E 320 -> 401 ms).
 template <int INTEG, int CLS, bool BVH>
@@ -1281,6 +1290,7 @@ struct iris_ctx {
     bool wfq_now = false;  // this render goes through the queue kernels
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     iris_stats stats = {};
+    uint64_t invariants[4] = {0, 0, 0, 0};  // debug build: the invariant counters of the last render
 };
 
 namespace {
@@ -1400,6 +1410,7 @@ bool use_register_kernel(const iris_ctx *c) {
 // The queue kernels serve scenes with a hierarchy whose BSDFs are Lambertian over constant spectra (one value for the four
 // wavelengths: 48 bytes of path state); mode 0 chooses them there, mode 2 keeps the register-resident kernel.
 bool use_queue_kernels(const iris_ctx *c) {
+    if (IRIS_DEBUG_INVARIANTS) return false;  // the invariant counters live in the kernels that shade without deferring
     if (c->multi_kernel || !(c->mode == 0 || c->mode == 3)) return false;  // mode 0: config D 112.9 ms against 118.8 ms for k_regwave's pooled traversal
     return c->sc.n_bvh_nodes != 0u && c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;
 }
@@ -1649,7 +1660,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         if (!c->scratch_ptr) return fail(c, IRIS_E_STATE, "the static workspace was not found at iris_ctx_create");
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-        const size_t o_counters = carve(17 * sizeof(unsigned long long)), o_cursor = carve(sizeof(unsigned long long));
+        const size_t o_counters = carve(IRIS_N_COUNTERS * sizeof(unsigned long long)), o_cursor = carve(sizeof(unsigned long long));
         const size_t o_sky = carve(use_sky ? npix : 0), o_xq = carve(xq_waves * PQ_FIELDS * XQ_CAP * sizeof(uint32_t));
         const size_t o_stack = carve(stack_hi_words * sizeof(uint32_t));
         const size_t o_park = carve(park_words * sizeof(uint32_t));
@@ -1725,7 +1736,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         ws.stack_hi = c->d_stack_hi;
         ws.park = c->d_park;
     }
-    HIP_TRY(c, hipMemsetAsync(ws.counters, 0, 17 * sizeof(unsigned long long), stream));
+    HIP_TRY(c, hipMemsetAsync(ws.counters, 0, IRIS_N_COUNTERS * sizeof(unsigned long long), stream));
     if (use_sky) {
         hipLaunchKernelGGL(k_sky_mask, dim3((npix + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, cam_dev(cam), frame_dev(p), c->sc.spheres, c->sc.n_prims, ws.sky);
         HIP_TRY(c, hipGetLastError());
@@ -1802,11 +1813,11 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         c->stats.chunks += 1;
     }
     unsigned long long *h = c->h_counters;  // pinned: the copy needs no staging buffer
-    HIP_TRY(c, hipMemcpyAsync(h, ws.counters, 17 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipMemcpyAsync(h, ws.counters, IRIS_N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
 #ifdef IRIS_PHASE_TIMERS
     {
-        unsigned long long t[17];
+        unsigned long long t[IRIS_N_COUNTERS];
         (void)hipMemcpy(t, ws.counters, sizeof t, hipMemcpyDeviceToHost);
         const double tot = (double)(t[4] + t[5] + t[6] + t[7]);
         std::fprintf(stderr, "[phase timers] extend %.1f%% generate %.1f%% refill %.1f%% shade %.1f%% (wave-cycles %.3g)\n", 100.0 * t[4] / tot,
@@ -1844,6 +1855,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     c->stats.resolve_ms = resolve_ms;
     c->stats.bvh_depth = c->bvh_depth;
     c->stats.sky_samples = h[10];
+    for (int k = 0; k < 4; k++) c->invariants[k] = h[20 + k];
     c->stats.kernel = wfq ? IRIS_KERNEL_QUEUES : (reg ? IRIS_KERNEL_REGISTER : (c->multi_kernel ? IRIS_KERNEL_POOL_STAGES : IRIS_KERNEL_POOL_FUSED));
     return IRIS_OK;
 }
@@ -1863,10 +1875,10 @@ int iris_ctx_create(int device, iris_ctx **out) {
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return IRIS_E_HIP; }
     c->n_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&c->d_counters, 17 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_counters, IRIS_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&c->d_work_cursor, sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_counters, 17 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_counters, IRIS_N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         scratch_for_device(device, &c->scratch_ptr) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
         iris_ctx_destroy(c);
@@ -2171,6 +2183,17 @@ int iris_render(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     }
     dev_free(d_out);
     return rc;
+}
+
+int iris_get_invariant_counts(const iris_ctx *c, uint64_t out[4]) {
+    if (!c || !out) return IRIS_E_ARG;
+#if IRIS_DEBUG_INVARIANTS
+    for (int k = 0; k < 4; k++) out[k] = c->invariants[k];
+    return IRIS_OK;
+#else
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    return IRIS_E_STATE;  // this build of the library does not count them (libiris_hip_debug.so does)
+#endif
 }
 
 int iris_get_stats(const iris_ctx *c, iris_stats *out) {

@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IRIS_HIP_LIB") or os.path.join(HERE, "lib", "libiris_hip.so")
 # The opt-in relaxed-arithmetic build of the same sources (iris_device.h, IRIS_RELAXED): never loaded unless asked for.
 LIB_RELAXED_PATH = os.path.join(HERE, "lib", "libiris_hip_relaxed.so")
+# The debug-invariants build (-DIRIS_DEBUG_INVARIANTS=1): counts where the reference's debug build would have panicked.
+LIB_DEBUG_PATH = os.path.join(HERE, "lib", "libiris_hip_debug.so")
 
 IRIS_OK = 0
 TRACE_MAX_DEPTH = 64
@@ -21,7 +23,7 @@ EXPORTS = (
     "iris_ctx_create", "iris_ctx_destroy", "iris_last_error", "iris_ctx_set_option", "iris_scene_upload",
     "iris_camera_new", "iris_roughness_to_alpha", "iris_render", "iris_render_device", "iris_render_device_noalloc",
     "iris_noalloc_workspace_bytes", "iris_film_to_rgb",
-    "iris_get_stats", "iris_allreduce_films", "iris_allreduce_shutdown", "iris_render_multi", "iris_sample_range", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
+    "iris_get_stats", "iris_get_invariant_counts", "iris_allreduce_films", "iris_allreduce_shutdown", "iris_render_multi", "iris_sample_range", "iris_upsample_table_load", "iris_upsample_table_free", "iris_upsample_table_resolution",
     "iris_upsample_get_spectrum", "iris_upsample_get_spectrum_hdr", "iris_upsample_table_upload", "iris_upsample_get_spectrum_hdr_batch", "iris_envmap_tables", "iris_oct_to_dir", "iris_dir_to_oct",
     "iris_envmap_from_latlong", "iris_envmap_texels_from_rgb", "iris_hdr_read", "iris_dbg_sampler", "iris_dbg_raygen", "iris_dbg_intersect", "iris_dbg_trace",
 )
@@ -86,10 +88,10 @@ class Trace(C.Structure):
 _libs = {}
 
 
-def load(relaxed=False):
+def load(relaxed=False, debug=False):
     """Load libiris_hip.so (relaxed: libiris_hip_relaxed.so, the opt-in build whose film is not the reference's bit for bit);
     raises IrisError if it has not been built (python -m iris_amd.build)."""
-    path = LIB_RELAXED_PATH if relaxed else LIB_PATH
+    path = LIB_DEBUG_PATH if debug else (LIB_RELAXED_PATH if relaxed else LIB_PATH)
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -112,6 +114,7 @@ def load(relaxed=False):
         "iris_noalloc_workspace_bytes": (C.c_size_t, []),
         "iris_film_to_rgb": (C.c_int, [fp, C.c_size_t, fp]),
         "iris_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "iris_get_invariant_counts": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "iris_allreduce_films": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_size_t]),
         "iris_allreduce_shutdown": (None, []),
         "iris_render_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(Camera), C.POINTER(RenderParams), fp]),

@@ -64,10 +64,10 @@ class Render:
 class HipWavefront:
     """One GPU's wavefront path tracer (an iris_ctx)."""
 
-    def __init__(self, device=0, relaxed=False, **options):
+    def __init__(self, device=0, relaxed=False, debug=False, **options):
         """relaxed: the opt-in build whose radiometric arithmetic uses 1-ulp reciprocals/roots and contraction (faster; the film
         then meets the statistical image gate, not the reference's bits).  Default: the exact build."""
-        self.L = ffi.load(relaxed=relaxed)
+        self.L = ffi.load(relaxed=relaxed, debug=debug)  # debug: libiris_hip_debug.so, which counts the reference's debug invariants
         self.ctx = C.c_void_p()
         rc = self.L.iris_ctx_create(int(device), C.byref(self.ctx))
         if rc != ffi.IRIS_OK:
@@ -149,6 +149,13 @@ class HipWavefront:
         st = ffi.Stats()
         _check(self.L, self.ctx, self.L.iris_get_stats(self.ctx, C.byref(st)), "iris_get_stats")
         return st
+
+    def invariant_counts(self):
+        """[Vec3 not finite, SpectralSample negative/NaN, PdfSet negative/NaN, light point off its sphere] of the last render:
+        where the reference's debug build would have panicked (debug=True contexts only; IrisError otherwise)."""
+        out = (C.c_uint64 * 4)()
+        _check(self.L, self.ctx, self.L.iris_get_invariant_counts(self.ctx, out), "iris_get_invariant_counts")
+        return [int(v) for v in out]
 
     # -- stage-level parity entry points ----------------------------------
     @staticmethod

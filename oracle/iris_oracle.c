@@ -708,6 +708,21 @@ typedef struct { sphere_t geometry; int light_index; int material_index; } primi
 
 static __thread orc_stats *t_stats; /* per-thread counters for the flop model */
 
+/* Where the reference's DEBUG build would have panicked: its debug_assert!s on the hot path, evaluated at a fixed
+ * list of check points per shaded bounce and counted instead of aborting -- the same list the -DIRIS_DEBUG_INVARIANTS build of the
+ * kernels counts (iris_device.h), so the two totals must be equal:
+ *   [0] Vec3 not finite (vec3.rs:24-31): the hit's frame (point, normal, tangeant, bitangeant); the next ray (origin, direction)
+ *   [1] SpectralSample negative or NaN (sample.rs:64-73): the path's radiance after the bounce's light; its throughput after the update
+ *   [2] PdfSet negative or NaN (pdf.rs:49-58): the pdfs of the sampled continuation; the path pdfs after the update (HWSS)
+ *   [3] the cone-sampled light point off its sphere by more than 2 % (sphere.rs:131-132) */
+static uint64_t g_inv[4];
+static inline void inv_count(int k) { __atomic_fetch_add(&g_inv[k], 1, __ATOMIC_RELAXED); }
+static inline int v3_bad(v3 a) { return !(isfinite(a.x) && isfinite(a.y) && isfinite(a.z)); }
+static inline int f4_bad(f4 a) { return !(a.v[0] >= 0.0f && a.v[1] >= 0.0f && a.v[2] >= 0.0f && a.v[3] >= 0.0f); }
+void orc_invariant_counts(uint64_t out[4], int reset) {
+    for (int k = 0; k < 4; k++) out[k] = reset ? __atomic_exchange_n(&g_inv[k], 0, __ATOMIC_RELAXED) : __atomic_load_n(&g_inv[k], __ATOMIC_RELAXED);
+}
+
 /* sphere.rs:25-74 */
 static int sphere_intersect(const sphere_t *sp, const ray_t *ray, isect_t *hit, float *t_out) {
     if (t_stats) t_stats->sphere_tests++;
@@ -777,6 +792,10 @@ static void sphere_sample(const sphere_t *sp, const isect_t *hit, sampler_t *sam
     v3 normal = v3_spherical_direction(sin_alpha, cos_alpha, phi, v3_neg(wc_x), v3_neg(wc_y), v3_neg(wc));
     v3 sampled_point_local = v3_smul(sp->radius, v3_normalize(normal));
     v3 sampled_point_world = v3_add(sp->position, sampled_point_local); /* local_to_world, sphere.rs:18-20 */
+    {   /* sphere.rs:131-132 */
+        const float dist = p3_distance(sampled_point_world, sp->position);
+        if (!(dist >= sp->radius * 0.98f) || !(dist <= sp->radius * 1.02f)) inv_count(3);
+    }
     *p_out = sampled_point_world;
     *pdf_out = pdf_cone(cos_theta_max);
 }
@@ -1382,15 +1401,21 @@ static f4 integrator_radiance(const orc_scene *sc, uint32_t integrator, const in
             if (t_stats) t_stats->bounces++;
         }
 
+        if (v3_bad(hit.point) || v3_bad(hit.normal) || v3_bad(hit.tangeant) || v3_bad(hit.bitangeant)) inv_count(0);
+        if (f4_bad(radiance)) inv_count(1);
+
         v3 shading_wo = world_to_shading(&hit, v3_neg(ray.d));
         v3 wi;
         f4 bsdf_values, bsdf_pdfs;
         bsdf_sample(sc, bsdf, shading_wo, wl, sampler, &wi, &bsdf_values, &bsdf_pdfs);
+        if (f4_bad(bsdf_pdfs)) inv_count(2);
         float cos_theta = fabsf(sh_cos_theta(wi));
         if (f4_hero(bsdf_pdfs) == 0.0f || cos_theta == 0.0f) break;
 
         throughput = f4_mul(throughput, f4_divs(f4_muls(bsdf_values, cos_theta), f4_hero(bsdf_pdfs)));
         if (hwss) path_pdfs = f4_mul(path_pdfs, bsdf_pdfs);
+        if (f4_bad(throughput)) inv_count(1);
+        if (hwss && f4_bad(path_pdfs)) inv_count(2);
 
         if (bounces >= ic->min_depth) {
             float p = rmin(f4_sum(throughput), 0.95f);
@@ -1399,6 +1424,7 @@ static f4 integrator_radiance(const orc_scene *sc, uint32_t integrator, const in
         }
         v3 world_wi = shading_to_world(&hit, wi);
         ray = ray_spawn(hit.point, world_wi, hit.normal);
+        if (v3_bad(ray.o) || v3_bad(ray.d)) inv_count(0);
     }
     if (hwss) return radiance;
     return f4_new(f4_hero(radiance), 0.0f, 0.0f, 0.0f);

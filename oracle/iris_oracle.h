@@ -162,6 +162,11 @@ void orc_pixel_xyz(const orc_scene *s, const orc_camera *cam, const orc_params *
 double orc_render(const orc_scene *s, const orc_camera *cam, const orc_params *p, int nthreads,
                   float *film_xyz, float *film_rgb, orc_stats *stats);
 
+/* How often, since the library was loaded or the counts were last reset, the reference's DEBUG build would have panicked on the
+ * hot path (its debug_assert!s: vec3.rs:24-31, sample.rs:64-73, pdf.rs:49-58, sphere.rs:131-132), at the check points listed in
+ * iris_oracle.c: out[0] non-finite Vec3, [1] negative/NaN SpectralSample, [2] negative/NaN PdfSet, [3] light point off its sphere. */
+void orc_invariant_counts(uint64_t out[4], int reset);
+
 #ifdef __cplusplus
 }
 #endif

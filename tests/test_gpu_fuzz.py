@@ -66,12 +66,9 @@ def random_scene(rng, table, n_spheres, with_env):
     return s
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("IRIS_FUZZ_SEEDS", "48"))))  # IRIS_FUZZ_SEEDS=1000 for a soak
-def test_random_scene_film_bit_exact(gpu, oracle, seed):
-    import iris_amd
-    from iris_amd import Render, UpsampleTable
+def fuzz_case(seed, table):
+    """Scene and render parameters of fuzz case `seed` (the random stream is left where the render seed and the camera come next)."""
     rng = np.random.RandomState(1000 + seed)
-    table = UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff"))
     n_spheres = int(rng.choice([1, 2, 5, 12, 40, 90]))  # >= 65: hierarchy
     if os.environ.get("IRIS_FUZZ_BIG") == "1":  # a soak of the hierarchy alone: deeper trees
         n_spheres = int(rng.choice([90, 300, 1000]))
@@ -81,7 +78,15 @@ def test_random_scene_film_bit_exact(gpu, oracle, seed):
     max_depth = int(rng.choice([1, 4, 15, 40]))
     w, h, spp = int(rng.randint(8, 50)), int(rng.randint(8, 40)), int(rng.randint(1, 10))
     scale = int(os.environ.get("IRIS_FUZZ_SCALE", "1"))  # IRIS_FUZZ_SCALE=6: 36 times the samples per scene, for rare events
-    w, h = w * scale, h * scale
+    return rng, scene, n_spheres, with_env, integrator, max_depth, w * scale, h * scale, spp
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("IRIS_FUZZ_SEEDS", "48"))))  # IRIS_FUZZ_SEEDS=1000 for a soak
+def test_random_scene_film_bit_exact(gpu, oracle, seed):
+    import iris_amd
+    from iris_amd import Render, UpsampleTable
+    table = UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff"))
+    rng, scene, n_spheres, with_env, integrator, max_depth, w, h, spp = fuzz_case(seed, table)
     oracle.set_trig_mode(oracle.TRIG_IRIS)
     try:
         flat = gpu.upload(scene)
