@@ -290,9 +290,10 @@ int iris_render(iris_ctx *ctx, const iris_camera *camera, const iris_render_para
 int iris_render_device(iris_ctx *ctx, const iris_camera *camera, const iris_render_params *params,
                        float *d_out_xyz, void *stream);
 
-/* iris_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same film bit for bit, same
- * stats; but every byte of device memory the render needs beyond the scene, the inputs and d_out_xyz -- the
+/* iris_render_device for callers that cannot allocate (harnesses and processes that forbid hipMalloc or whose
+ * device memory is budgeted elsewhere).  It has no counterpart in the reference.  Like iris_render_device it waits for
+ * `stream` before it returns (the stats are read back), so it cannot be called under HIP stream capture.  Same
+ * arguments, same film bit for bit, same stats; but every byte of device memory the render needs beyond the scene, the inputs and d_out_xyz -- the
  * per-sample result buffer (12 bytes per camera sample of the call), the sky mask, the work counters and the per-wave
  * queues -- comes out of one static __device__ array of iris_noalloc_workspace_bytes() (64 MiB) that each GPU the
  * library runs on holds until the process ends, so the call makes no hipMalloc/hipFree (nor does it go through any

@@ -1634,7 +1634,7 @@ IRIS_DEV V3 env_sample(const SceneDev &sc, float u0, float u1) {
 IRIS_RADIOMETRIC_END
 // ---------------------------------------------------------------- path state and the two stages' per-lane work
 // -DIRIS_DEBUG_INVARIANTS=1 (libiris_hip_debug.so): the debug_assert!s of the reference's hot path, counted instead of trapping, at a
-// fixed list of check points per shaded bounce -- the list oracle/iris_oracle.c counts too, so the totals are comparable:
+// fixed list of check points per shaded bounce -- the list the CPU checker of the tests counts too, so the totals are comparable:
 //   inv[0] Vec3 not finite (vec3.rs:24-31): the hit's frame; the next ray           inv[1] SpectralSample negative or NaN (sample.rs:64-73):
 //   radiance after the bounce's light, throughput after its update   inv[2] PdfSet negative or NaN (pdf.rs:49-58): the sampled
 //   continuation's pdfs, the path pdfs after the update (HWSS)       inv[3] cone-sampled light point off its sphere by > 2 % (sphere.rs:131-132)

@@ -1631,7 +1631,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     int64_t per_cu = reg ? c->reg_blocks_per_cu : c->blocks_per_cu;
     if (no_alloc) per_cu = std::min<int64_t>(per_cu, 4);  // a CU holds at most 4 of these workgroups; a smaller grid keeps the per-wave queues small
     const bool pooled = reg && c->sc.n_bvh_nodes && c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;  // k_regwave<.., LAMBERT_CONSTANT, true>: the ray pool
-    if (pooled) per_cu = std::min<int64_t>(per_cu, 4);    // three are resident; every lane of the grid owns a parking area in global memory
+    if (pooled) per_cu = std::min<int64_t>(per_cu, no_alloc ? 3 : 4);  // three are resident; every lane of the grid owns a parking area in global memory (the static workspace pays for residents only)
     if (per_cu == 0) {
         const size_t dyn = (size_t)sphere_cap_for(c) * sizeof(float4);
         switch (p->integrator) {
@@ -1657,7 +1657,10 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     Workspace ws;
     if (no_alloc) {
         // everything comes out of this device's copy of the static array; one chunk, so no running sums are needed
-        if (!c->scratch_ptr) return fail(c, IRIS_E_STATE, "the static workspace was not found at iris_ctx_create");
+        if (!c->scratch_ptr) {  // the lookup at iris_ctx_create failed: once more, and this time the failure is this call's error
+            hipError_t e = scratch_for_device(c->device, &c->scratch_ptr);
+            if (e != hipSuccess) return fail(c, IRIS_E_HIP, std::string("the static workspace of iris_render_device_noalloc was not found on this device: ") + hipGetErrorString(e));
+        }
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         const size_t o_counters = carve(IRIS_N_COUNTERS * sizeof(unsigned long long)), o_cursor = carve(sizeof(unsigned long long));
@@ -1879,11 +1882,12 @@ int iris_ctx_create(int device, iris_ctx **out) {
         hipMalloc((void **)&c->d_live, sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&c->d_work_cursor, sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_live, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&c->h_counters, IRIS_N_COUNTERS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
-        scratch_for_device(device, &c->scratch_ptr) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
         iris_ctx_destroy(c);
         return IRIS_E_HIP;
     }
+    // only iris_render_device_noalloc needs the static workspace: a failed lookup is retried, and reported, there
+    if (scratch_for_device(device, &c->scratch_ptr) != hipSuccess) { c->scratch_ptr = nullptr; (void)hipGetLastError(); }
     *out = c;
     return IRIS_OK;
 }

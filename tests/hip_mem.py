@@ -24,6 +24,7 @@ def hip():
         _hip.hipFree.argtypes = [C.c_void_p]
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        _hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     return _hip
 
 
@@ -79,3 +80,11 @@ def to_host(ptr, shape, dtype):
 
 def synchronize():
     assert hip().hipDeviceSynchronize() == 0
+
+
+def free_bytes():
+    """Free device memory on the current GPU as the runtime reports it (hipMemGetInfo)."""
+    free_, total = C.c_size_t(), C.c_size_t()
+    assert hip().hipDeviceSynchronize() == 0
+    assert hip().hipMemGetInfo(C.byref(free_), C.byref(total)) == 0
+    return free_.value

@@ -65,6 +65,38 @@ def test_noalloc_other_scene_classes(scene_name):
         assert first.any() and second.any()
 
 
+@pytest.mark.parametrize("scene_name", ["s1", "s3", "s3env", "s2_small"])
+def test_noalloc_leaves_free_device_memory_unchanged(scene_name):
+    """The claim itself: on a context that has never rendered (so nothing a render allocates on demand exists yet), the
+    call changes the GPU's free memory by nothing, per scene class; iris_render_device on the same fresh state does
+    allocate (which shows that the probe sees allocations of this size).  One earlier no-alloc call in ANOTHER context
+    loads the kernels first: what the HIP runtime sets up at a kernel's first launch is not the library's."""
+    import os
+    import iris_amd
+    from hip_mem import DeviceFilm, free_bytes
+    from iris_amd import EnvMap, Render, Scene, UpsampleTable
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    scene = {"s1": Scene.dummy, "s3": Scene.glossy_dielectric, "s3env": Scene.glossy_dielectric, "s2_small": lambda: Scene.many_spheres(600)}[scene_name]()
+    if scene_name == "s3env":
+        scene.env_map = EnvMap.sky(UpsampleTable(os.path.join(gold, "srgb_res16.coeff")), 64, 64)
+    render = Render(256, 160, 16, scene, max_depth=32)  # 7.9 MB of results: far above the probe's granularity
+    film = DeviceFilm(render.height, render.width)
+    with iris_amd.HipWavefront(0) as warm:
+        warm.upload(scene)
+        warm.render_film_device_noalloc(render, film.data_ptr())
+    with iris_amd.HipWavefront(0) as g:
+        g.upload(scene)
+        before = free_bytes()
+        g.render_film_device_noalloc(render, film.data_ptr())
+        after_first = free_bytes()
+        g.render_film_device_noalloc(Render(128, 96, 4, scene, max_depth=32), film.data_ptr())
+        after_second = free_bytes()
+        assert after_first == before and after_second == before, (before, after_first, after_second)
+        g.render_film_device(render, film.data_ptr())
+        assert free_bytes() < before  # the allocating entry point does show on this probe
+    film.free()
+
+
 def test_noalloc_limits_are_errors():
     import iris_amd
     from hip_mem import DeviceFilm
