@@ -29,6 +29,26 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
         print("  %-46s VGPR %s accum %s SGPR %s LDS %s scratch %s grid %s wg %s" % (
             k[:46], row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"),
             row.get("Scratch_Size"), row.get("Grid_Size"), row.get("Workgroup_Size")))
+# The path-tracing stage of a step may be many dispatches that overlap on several streams (queue kernels): their durations
+# add up to more than the stage takes.  The comparable figure is the span from the first start to the last end of the
+# stage's dispatches between two k_resolve dispatches -- what bench.py's HIP events around the stage measure.
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    spans, lo, hi, n = [], None, None, 0
+    for row in rows:
+        k = short(row["Kernel_Name"])
+        if k.startswith("k_resolve"):
+            if lo is not None:
+                spans.append(((hi - lo) / 1e6, n))
+            lo = hi = None
+            n = 0
+        elif k.startswith("k_") and not k.startswith(("k_sky_mask", "k_upsample", "k_dbg")):
+            a, b = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+            lo, hi, n = (a if lo is None else min(lo, a)), (b if hi is None else max(hi, b)), n + 1
+    if spans:
+        print("== path-tracing stage per step: first start to last end of its dispatches (ms; dispatches) ==")
+        print("   " + "  ".join("%.3f (%d)" % s for s in spans) + "   mean of all but the first (warm-up): %.3f" %
+              (sum(s[0] for s in spans[1:]) / max(1, len(spans) - 1)))
 print("== PMC counters per kernel: sum over all dispatches of all passes that collected the counter, and per dispatch ==")
 agg = defaultdict(lambda: defaultdict(float))
 ndisp = defaultdict(set)
