@@ -198,9 +198,10 @@ const char *iris_last_error(const iris_ctx *ctx);
  *                     scans traverse it (default 65; 0 = never: every scan tests every sphere like scene.rs:116-166).
  *                     Closest hit and tie rule are the list scan's; iris_stats.sphere_tests then counts the tests made
  *   "bvh_leaf"        spheres per leaf of the hierarchy, 1..7 (default 2)
- *   "x_park_max", "x_fire"  register-resident kernel, scenes with non-Lambertian BSDFs and no environment map: hits on
- *                     such surfaces are set aside and shaded together; a mixed iteration runs when this many lanes
- *                     wait with one (1..64, default 24) or this many primary ones are queued (1..129, default 110)
+ *   "sort_kinds"      register-resident kernel, scenes with more than one kind of BSDF: 1 (default): every wave sorts its hits by
+ *                     BSDF kind through stacks of path records in global memory (28 KiB per kind and wave, 448 MiB per GPU),
+ *                     so that a shade iteration runs one BSDF's code with nearly all lanes; 0: an iteration shades whatever
+ *                     the lanes hold (what iris_render_device_noalloc does: the stacks do not fit its workspace)
  *   "sky_mask"        1 (default): scenes of up to 64 spheres without an environment map: a pre-pass marks the pixels
  *                     whose camera samples provably hit nothing (conservative cone test in binary64); they are exactly
  *                     black in the reference and are neither traced nor stored; 0: every sample is traced

@@ -610,7 +610,7 @@ IRIS_RADIOMETRIC_END
 struct SceneDev {
     const float4 *spheres;      // (cx, cy, cz, r), primitive order
     const int4 *prim_info;      // (material_index, light_index, bits of albedo / PI when the material is Lambertian over a constant spectrum, 0); -1 = None
-    const unsigned char *prim_kind;  // 0: Lambertian material or none; 1: any other BSDF (the register kernel sets those hits aside)
+    const unsigned char *prim_kind;  // the kind of the primitive's BSDF (IRIS_BSDF_*), 0 for Lambertian, none or absorbing: the register kernel sorts hits by it
     const iris_bsdf *bsdfs;
     const iris_spectrum *spectra;
     const float *spec_over_pi;  // per spectrum: c0 / PI for a constant spectrum (the IEEE quotient, formed once on the host)

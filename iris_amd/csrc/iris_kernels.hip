@@ -87,11 +87,9 @@ struct WfArgs {
     uint32_t *park;           // pooled traversal (hierarchy + Lambertian/constant class): IRIS_WALK_WORDS words per lane for parked rays, word-major
     uint32_t *stack_hi;       // register kernel with a hierarchy: traversal-stack entries beyond the LDS ones, entry-major
     uint32_t stack_lds_n;     // traversal-stack entries per lane kept in LDS
-    uint32_t *xq;             // register kernel, general classes: per wave, PQ_FIELDS x XQ_CAP words (see k_regwave)
+    uint4 *kq;                // register kernel, general classes, hits sorted by BSDF kind: per wave, KQ_KINDS stacks of KQ_CAP path records
     unsigned long long *work_cursor;  // register kernel: next unclaimed item of the launch (one counter in global memory, zeroed per launch)
     uint32_t work_run;        // register kernel: items a wave claims at a time (a multiple of 64)
-    uint32_t x_park_max;      // lanes allowed to wait with a non-Lambertian hit before a mixed iteration is run
-    uint32_t x_fire;          // queued non-Lambertian primary hits that trigger a mixed iteration
 };
 
 struct BlockShared {
@@ -347,14 +345,36 @@ k_wavefront(WfArgs a) {
 //              hits are compacted (ballot + prefix sum) into the wave's queue as an 11-dword record.
 //              Runs whenever fewer than PQ_LOW records are queued, always with a full wave.
 //   extend:    lanes whose path survived the last bounce intersect their new ray.
-//   refill:    lanes without a path pop a record each and become the first bounce of that path.
+//   refill:    lanes without a path pop a record each and become the first bounce of that path (general classes: hits are
+//              sorted by BSDF kind first, see below).
 //   shade:     every lane that holds a hit shades one bounce.
 // The expensive shade phase therefore runs with (nearly) every lane busy as long as work is left, and the
 // camera-sample code never runs for a handful of lanes.  No other wave touches a wave's queue, so no
 // synchronisation is needed.
-enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u, LANE_FIN = 4u };  // FIN: the path has ended, its last visibility query is still out
-constexpr uint32_t XQ_CAP = 128;  // second queue (non-Lambertian primary hits), in global memory
+enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u, LANE_FIN = 4u };  // HITX: holds a hit of a BSDF kind that is not this iteration's; FIN: the path has ended, its last visibility query is still out
 constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
+// General classes (SORTED), hits sorted by BSDF kind: a wave that shades hits on four BSDFs in one iteration runs ALL of that code for
+// a quarter of the lanes each, which is what halved the lane utilisation of such scenes (S3 52 %, config E 44 %).  So every wave owns one stack of whole path records per BSDF kind in global
+// memory (L2-resident: only the tops are touched).  Before a shade iteration the wave picks ONE kind -- the one it can fill most
+// lanes with -- moves the hits of the other kinds out of its lanes into their stacks and takes hits of the chosen kind in, so the
+// iteration runs one BSDF's code with (nearly) every lane instead of four BSDFs' code with a quarter of the lanes each.  A path is a
+// function of (pixel, sample index) only, so which lane and which iteration shade a bounce changes no value.  A record: ray origin +
+// hero wavelength, direction + bounce, throughput, path pdfs, radiance, sampler (scramble, index, item, draws), hit (prim, t): 7 x 16 B.
+// The lane's draw ring is not moved: the lane that takes a record generates the set in progress again (sampler_rewind), which costs no
+// extra pass of ensure_draws in most iterations (some lane needs the third set anyway).  Primary hits on Lambertian surfaces keep
+// their compact queue in LDS; primary hits on the other kinds go to their stack as whole records.
+// Measured (1920x1080x256, depth 32, HwssNaive): S3 55.7 -> 41.6 ms, lanes 52 -> 77 %, 11.5 records out and 21.8 in per iteration of
+// 63.2 lanes; config E 77.5 -> 61.9 ms, lanes 44 -> 64 %.  In flight per wave (KQ_LOW): 64 49.0 / 73.8 ms, 192 41.6 / 61.9, 448 42.1 /
+// 62.4, 960 42.4 / 62.7.  (The scheme this replaces set hits on non-Lambertian surfaces aside in the lanes and in a second primary
+// queue and shaded them together in "mixed" iterations: S3 71.5 -> 67.1 ms at the time, a loss under an environment map.)
+#ifndef IRIS_KQ_CAP
+#define IRIS_KQ_CAP 256u   // records per stack; at most KQ_CAP hits are in flight per wave (lanes + stacks + primary queue)
+#endif
+#ifndef IRIS_KQ_LOW
+#define IRIS_KQ_LOW 192u   // camera samples are generated while fewer hits than this are in flight (64 more may come of one round)
+#endif
+constexpr uint32_t KQ_KINDS = 4u, KQ_FIELDS = 7u, KQ_CAP = IRIS_KQ_CAP, KQ_LOW = IRIS_KQ_LOW;
+static_assert(KQ_LOW + 64u <= KQ_CAP, "a generate round adds up to 64 hits");
 // BVH (compile-time): the scene has a hierarchy.  Traversal is bound by the latency of dependent L2 reads, so
 // what counts is resident waves, and LDS is what limits them: the per-lane traversal stacks take 1 KiB per
 // level.  That variant therefore does without the Sobol nibble table (direction vectors come from the constant
@@ -398,23 +418,28 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     // result is a function of the item and goes to the item's own slot.
     uint32_t w_next = 0u, w_lim = 0u;  // wave-uniform: the unclaimed rest of this wave's current run
     uint32_t(*q)[PQ_CAP] = primq[threadIdx.x / 64];
-    // General scene classes: hits are of two kinds, Lambertian surfaces (cheap, the bulk) and the rest (GGX,
-    // dielectric, mirror: several times the code).  A wave that shades both in the same iteration runs ALL of
-    // that code for a handful of lanes each, which is what halves the lane utilisation of such scenes.  So hits
-    // of the second kind are set aside: primary ones go to a second queue (in global memory, L2-resident: it is
-    // used far less often), lanes whose continued path lands on one wait (LANE_HITX) while the wave keeps shading
-    // Lambertian hits, and when enough have gathered -- waiting lanes, a well-filled second queue, or nothing
-    // else left -- the wave runs a mixed iteration that takes them all at once.  Which iteration shades a hit
-    // changes no value: every path is a function of (pixel, sample index) only.
-    // (Measured: S3 71.5 -> 67.1 ms.  Under an environment map the light-pick branch and the CDF search dominate the
-    // divergence and the scheme costs 4 %, so that class keeps one kind.)
-    constexpr bool TWO_KINDS = CLS == IRIS_CLS_GENERAL;
+    constexpr bool SORTED = CLS != IRIS_CLS_LAMBERT_CONSTANT;  // (never POOLED: that is the Lambertian/constant class)
     // sky mask (k_sky_mask): short lists without an environment map only -- under a map a miss needs its ray
     const bool USE_SKY = !BVH && CLS != IRIS_CLS_GENERAL_ENV && a.sky != nullptr;
     uint32_t n_sky = 0u;
-    uint32_t *const xq = TWO_KINDS ? a.xq + (size_t)(blockIdx.x * (BLOCK / 64) + threadIdx.x / 64) * PQ_FIELDS * XQ_CAP : nullptr;
-    uint32_t x_head = 0u, x_count = 0u;  // wave-uniform
-    auto hit_is_x = [&](int prim_) -> bool { return TWO_KINDS && a.sc.prim_kind[prim_] != 0u; };
+    // SORTED: this wave's stacks, their fill (wave-uniform), the BSDF kind of the hit a lane holds
+    uint4 *const kq = SORTED ? a.kq + (size_t)(blockIdx.x * (BLOCK / 64) + threadIdx.x / 64) * (KQ_KINDS * KQ_FIELDS * KQ_CAP) : nullptr;
+    uint32_t kc[KQ_KINDS] = {0u, 0u, 0u, 0u};
+    uint32_t kind = 0u;
+    // (no stacks -- the scene holds one kind only, option sort_kinds = 0, or the entry point that may not allocate: every hit counts as kind 0,
+    // nothing is ever moved, and an iteration shades whatever the lanes hold)
+    const bool sort_on = SORTED && a.kq != nullptr;
+    auto kind_of = [&](int prim_) -> uint32_t { return sort_on ? (uint32_t)a.sc.prim_kind[prim_] : 0u; };
+    auto kq_store = [&](uint32_t k_, uint32_t slot_, const PathState &p_, uint32_t item_, int prim_, float t_) {
+        uint4 *r = kq + (size_t)k_ * (KQ_FIELDS * KQ_CAP) + slot_;
+        r[0 * KQ_CAP] = make_uint4(__float_as_uint(p_.ray.o.x), __float_as_uint(p_.ray.o.y), __float_as_uint(p_.ray.o.z), __float_as_uint(p_.hero_nm));
+        r[1 * KQ_CAP] = make_uint4(__float_as_uint(p_.ray.d.x), __float_as_uint(p_.ray.d.y), __float_as_uint(p_.ray.d.z), p_.bounce);
+        r[2 * KQ_CAP] = make_uint4(__float_as_uint(p_.thr.v[0]), __float_as_uint(p_.thr.v[1]), __float_as_uint(p_.thr.v[2]), __float_as_uint(p_.thr.v[3]));
+        if (INTEG < 2) r[3 * KQ_CAP] = make_uint4(__float_as_uint(p_.ppdf.v[0]), __float_as_uint(p_.ppdf.v[1]), __float_as_uint(p_.ppdf.v[2]), __float_as_uint(p_.ppdf.v[3]));
+        r[4 * KQ_CAP] = make_uint4(__float_as_uint(p_.rad.v[0]), __float_as_uint(p_.rad.v[1]), __float_as_uint(p_.rad.v[2]), __float_as_uint(p_.rad.v[3]));
+        r[5 * KQ_CAP] = make_uint4(p_.smp.scramble, p_.smp.index, item_, p_.smp.draws);
+        r[6 * KQ_CAP] = make_uint4((uint32_t)prim_, __float_as_uint(t_), 0u, 0u);
+    };
     Counters cnt = {0u, 0u, 0u, 0u};
     PathState ps;
     ps.ray.o = v3(0.0f, 0.0f, 0.0f); ps.ray.d = v3(0.0f, 0.0f, 1.0f); ps.hero_nm = LAMBDA_MIN_NM; ps.bounce = 0u;
@@ -501,7 +526,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                     t = t_new;
                     prim = prim_new;
                     if (prim >= 0) {
-                        lane_state = hit_is_x(prim) ? LANE_HITX : LANE_HIT;
+                        lane_state = LANE_HIT;
+                        if (SORTED) kind = kind_of(prim);
                     } else {  // `None => break` (hwss_naive.rs:41-44)
                         path_miss<INTEG, CLS>(a.sc, ps);
                         store_result(a, item, path_xyz<INTEG>(ps));
@@ -512,7 +538,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
         }
         IRIS_PHASE(0);
         // ---- generate: camera samples, 64 at a time, until a wave's worth of primary hits is queued ----
-        while (work_left && q_count < PQ_LOW && (!TWO_KINDS || x_count <= XQ_CAP - 64u)) {
+        // (SORTED: hits in flight -- in lanes, in the stacks, in the primary queue -- stay below KQ_CAP, which is what bounds every stack)
+        uint32_t in_flight = 0u;
+        if (SORTED) in_flight = (uint32_t)__popcll(__ballot(lane_state == LANE_HIT)) + q_count + kc[0] + kc[1] + kc[2] + kc[3];
+        while (work_left && q_count < PQ_LOW && (!SORTED || in_flight < KQ_LOW)) {
             if (w_next >= w_lim) {
                 unsigned long long claim = 0ull;  // 64 bits: every wave asks once too often, and grids and runs can be made large
                 if (lane_id() == 0u) claim = atomicAdd(a.work_cursor, (unsigned long long)a.work_run);
@@ -567,7 +596,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                 }
             }
             const bool hitp = live && prim_new >= 0;
-            const bool hitx = hitp && hit_is_x(prim_new);
+            uint32_t kind_new = 0u;
+            if (SORTED && hitp) kind_new = kind_of(prim_new);
+            const bool hitx = hitp && kind_new != 0u;
             const unsigned long long hmask = __ballot(hitp && !hitx);
             if (hitp && !hitx) {
                 const uint32_t e = (q_head + q_count + prefix_below(hmask)) % PQ_CAP;
@@ -577,54 +608,105 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                 q[9][e] = __float_as_uint(cs.u2); q[10][e] = __float_as_uint(cs.u3);
             }
             q_count += (uint32_t)__popcll(hmask);
-            if (TWO_KINDS) {
-                const unsigned long long xmask = __ballot(hitx);
-                if (hitx) {
-                    const uint32_t e = (x_head + x_count + prefix_below(xmask)) % XQ_CAP;
-                    xq[0 * XQ_CAP + e] = new_item; xq[1 * XQ_CAP + e] = sample_index; xq[2 * XQ_CAP + e] = cs.scramble;
-                    xq[3 * XQ_CAP + e] = __float_as_uint(cs.hero_nm);
-                    xq[4 * XQ_CAP + e] = __float_as_uint(cs.d.x); xq[5 * XQ_CAP + e] = __float_as_uint(cs.d.y); xq[6 * XQ_CAP + e] = __float_as_uint(cs.d.z);
-                    xq[7 * XQ_CAP + e] = __float_as_uint(t_new); xq[8 * XQ_CAP + e] = (uint32_t)prim_new;
-                    xq[9 * XQ_CAP + e] = __float_as_uint(cs.u2); xq[10 * XQ_CAP + e] = __float_as_uint(cs.u3);
+            if (SORTED) {
+                // primary hits on other BSDFs start their path here and go to the stack of their kind as whole records
+                in_flight += (uint32_t)__popcll(__ballot(hitp));
+                if (__ballot(hitx) != 0ull) {
+                    uint32_t slot = 0u;
+#pragma unroll
+                    for (uint32_t j = 1; j < KQ_KINDS; j++) {
+                        const unsigned long long m = __ballot(hitx && kind_new == j);
+                        if (hitx && kind_new == j) slot = kc[j] + prefix_below(m);
+                        kc[j] += (uint32_t)__popcll(m);
+                    }
+                    if (hitx) {
+                        PathState pn;
+                        pn.smp.scramble = cs.scramble; pn.smp.index = sample_index; pn.smp.draws = 2u; pn.smp.gen = 4u;  // as path_begin leaves it; the ring is
+                        pn.hero_nm = cs.hero_nm; pn.ray = ray; pn.bounce = 0u;                                           // filled again by whoever takes the record
+                        pn.thr = splat(1.0f); pn.ppdf = splat(1.0f); pn.rad = splat(0.0f);
+                        kq_store(kind_new, slot, pn, new_item, prim_new, t_new);
+                    }
                 }
-                x_count += (uint32_t)__popcll(xmask);
             }
             __builtin_amdgcn_wave_barrier();
         }
         IRIS_PHASE(1);
-        // ---- which kind of iteration (wave-uniform) ----
-        bool mixed = false;
-        if (TWO_KINDS) {
-            const uint32_t n_wait = (uint32_t)__popcll(__ballot(lane_state == LANE_HITX));
-            const bool plain_work = q_count != 0u || __ballot(lane_state == LANE_HIT) != 0ull;
-            mixed = (n_wait != 0u || x_count != 0u) &&
-                    (n_wait >= a.x_park_max || x_count >= a.x_fire || x_count > XQ_CAP - 64u || !plain_work);
-        }
-        // ---- refill: lanes without a path take a queued primary hit (a mixed iteration: of the second kind first) ----
-        {
-            uint32_t n_x = 0u;
-            if (TWO_KINDS && mixed) {
-                const bool dead = lane_state == LANE_DEAD;
-                const unsigned long long dmask = __ballot(dead);
-                const uint32_t n_dead = (uint32_t)__popcll(dmask);
-                n_x = n_dead < x_count ? n_dead : x_count;
-                const uint32_t rank = prefix_below(dmask);
-                if (dead && rank < n_x) {
-                    const uint32_t e = (x_head + rank) % XQ_CAP;
-                    item = xq[0 * XQ_CAP + e];
-                    CamSample cs;
-                    cs.scramble = xq[2 * XQ_CAP + e]; cs.hero_nm = __uint_as_float(xq[3 * XQ_CAP + e]);
-                    cs.d = v3(__uint_as_float(xq[4 * XQ_CAP + e]), __uint_as_float(xq[5 * XQ_CAP + e]), __uint_as_float(xq[6 * XQ_CAP + e]));
-                    cs.u2 = __uint_as_float(xq[9 * XQ_CAP + e]); cs.u3 = __uint_as_float(xq[10 * XQ_CAP + e]);
-                    path_begin(a.cam, cs, xq[1 * XQ_CAP + e], ring, ps);
-                    t = __uint_as_float(xq[7 * XQ_CAP + e]);
-                    prim = (int)xq[8 * XQ_CAP + e];
-                    lane_state = LANE_HITX;
+        // ---- SORTED: pick the BSDF kind of this iteration, move the other kinds' hits out and hits of that kind in ----
+        if (SORTED) {
+            uint32_t best = 0u, best_score = 0u, sel_count = 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < KQ_KINDS; j++) {
+                const uint32_t n_lane = (uint32_t)__popcll(__ballot(lane_state == LANE_HIT && kind == j));
+                const uint32_t avail = n_lane + kc[j] + (j == 0u ? q_count : 0u);
+                const uint32_t score = (avail < 64u ? avail : 64u) * 128u + n_lane;  // most lanes filled; among equals, fewest records moved
+                if (score > best_score) { best_score = score; best = j; sel_count = kc[j]; }
+            }
+            if (best_score != 0u) {
+                const uint32_t supply = sel_count + (best == 0u ? q_count : 0u);
+                const bool dead = lane_state == LANE_DEAD, other = lane_state == LANE_HIT && kind != best;
+                const unsigned long long dmask = __ballot(dead), omask = __ballot(other);
+                const uint32_t n_dead = (uint32_t)__popcll(dmask), n_other = (uint32_t)__popcll(omask);
+                const uint32_t fill_dead = n_dead < supply ? n_dead : supply;
+                const uint32_t n_evict = n_other < supply - fill_dead ? n_other : supply - fill_dead;  // a hit is moved out only if one of the chosen kind takes its lane
+                const bool evict = other && prefix_below(omask) < n_evict;
+#ifdef IRIS_PHASE_TIMERS
+                ph_mixed += 1ull; ph_mixed_lanes += n_evict; ph_mixed_x += (fill_dead + n_evict < sel_count ? fill_dead + n_evict : sel_count); ph_kind[best & 3u] += 1ull;
+#endif
+                if (n_evict != 0u) {
+                    uint32_t slot = 0u;
+#pragma unroll
+                    for (uint32_t j = 0; j < KQ_KINDS; j++) {
+                        const unsigned long long m = __ballot(evict && kind == j);
+                        if (evict && kind == j) slot = kc[j] + prefix_below(m);
+                        kc[j] += (uint32_t)__popcll(m);
+                    }
+                    if (evict) kq_store(kind, slot, ps, item, prim, t);
                 }
-                x_head = (x_head + n_x) % XQ_CAP;
-                x_count -= n_x;
+                const bool fill = evict || (dead && prefix_below(dmask) < fill_dead);
+                const unsigned long long fmask = __ballot(fill);
+                const uint32_t n_fill = fill_dead + n_evict, rank = prefix_below(fmask);
+                const uint32_t n_pop = n_fill < sel_count ? n_fill : sel_count;
+                if (fill && rank < n_pop) {
+                    const uint4 *r = kq + (size_t)best * (KQ_FIELDS * KQ_CAP) + (sel_count - 1u - rank);
+                    const uint4 f0 = r[0 * KQ_CAP], f1 = r[1 * KQ_CAP], f2 = r[2 * KQ_CAP], f4_ = r[4 * KQ_CAP], f5 = r[5 * KQ_CAP], f6 = r[6 * KQ_CAP];
+                    ps.ray.o = v3(__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z)); ps.hero_nm = __uint_as_float(f0.w);
+                    ps.ray.d = v3(__uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z)); ps.bounce = f1.w;
+                    ps.thr = f4(__uint_as_float(f2.x), __uint_as_float(f2.y), __uint_as_float(f2.z), __uint_as_float(f2.w));
+                    if (INTEG < 2) { const uint4 f3 = r[3 * KQ_CAP]; ps.ppdf = f4(__uint_as_float(f3.x), __uint_as_float(f3.y), __uint_as_float(f3.z), __uint_as_float(f3.w)); }
+                    else ps.ppdf = splat(1.0f);
+                    ps.rad = f4(__uint_as_float(f4_.x), __uint_as_float(f4_.y), __uint_as_float(f4_.z), __uint_as_float(f4_.w));
+                    ps.smp.scramble = f5.x; ps.smp.index = f5.y; item = f5.z; ps.smp.draws = f5.w;
+                    sampler_rewind(ps.smp);  // this lane's ring holds another path's values
+                    prim = (int)f6.x; t = __uint_as_float(f6.y);
+                    kind = best;
+                    lane_state = LANE_HIT;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < KQ_KINDS; j++) if (j == best) kc[j] -= n_pop;
+                // the rest of the lanes to fill (Lambertian iterations only): primary hits from the queue
+                const uint32_t n_q = n_fill - n_pop;
+                if (fill && rank >= n_pop) {
+                    const uint32_t e = (q_head + (rank - n_pop)) % PQ_CAP;
+                    item = q[0][e];
+                    CamSample cs;
+                    cs.scramble = q[2][e]; cs.hero_nm = __uint_as_float(q[3][e]);
+                    cs.d = v3(__uint_as_float(q[4][e]), __uint_as_float(q[5][e]), __uint_as_float(q[6][e]));
+                    cs.u2 = __uint_as_float(q[9][e]); cs.u3 = __uint_as_float(q[10][e]);
+                    path_begin(a.cam, cs, q[1][e], ring, ps);
+                    t = __uint_as_float(q[7][e]);
+                    prim = (int)q[8][e];
+                    kind = 0u;
+                    lane_state = LANE_HIT;
+                }
+                q_head = (q_head + n_q) % PQ_CAP;
+                q_count -= n_q;
                 __builtin_amdgcn_wave_barrier();
             }
+            // lanes that hold a hit of another kind (none of the chosen kind was left to take their place) sit this iteration out
+            if (lane_state == LANE_HIT && kind != best) lane_state = LANE_HITX;
+        }
+        // ---- refill: lanes without a path take a queued primary hit ----
+        if (!SORTED) {
             const bool dead = lane_state == LANE_DEAD;
             const unsigned long long dmask = __ballot(dead);
             const uint32_t n_dead = (uint32_t)__popcll(dmask);
@@ -648,10 +730,10 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
         }
         IRIS_PHASE(2);
         // ---- shade ----
-        const bool active = lane_state == LANE_HIT || (mixed && lane_state == LANE_HITX);
+        const bool active = lane_state == LANE_HIT;
+        if (SORTED && lane_state == LANE_HITX) lane_state = LANE_HIT;  // back in the count for the next iteration's choice
         if (__ballot(active) == 0ull) {
-            // Nothing to shade.  Without work left that is the end: a plain iteration is only chosen when nothing of
-            // the second kind waits or plain work exists, so no lane holds a hit and both queues are empty.
+            // Nothing to shade.  Without work left that is the end: no lane holds a hit and the queue (SORTED: and every stack) is empty.
             // (POOLED: paths may still wait for rays that are out, walkers may hold parked rays: the next loop top moves them on.)
             if (!work_left && (!POOLED || (__ballot(lane_state != LANE_DEAD) == 0ull && __ballot(walking) == 0ull))) break;
             continue;  // every camera sample of the last generate phase missed: generate again
@@ -659,11 +741,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
 #ifdef IRIS_PHASE_TIMERS
         ph_lanes += (unsigned long long)__popcll(__ballot(active));
         ph_iters += 1ull;
-        if (mixed) {
-            int kd = -1;
-            if (lane_state == LANE_HITX && prim >= 0) { const int m_ = a.sc.prim_info[prim].x; kd = m_ >= 0 ? (int)a.sc.bsdfs[m_].kind : -1; }
-            for (int kk = 1; kk <= 3; kk++) ph_kind[kk] += (unsigned long long)__popcll(__ballot(kd == kk));
-            ph_mixed += 1ull; ph_mixed_lanes += (unsigned long long)__popcll(__ballot(active)); ph_mixed_x += (unsigned long long)__popcll(__ballot(lane_state == LANE_HITX)); }
 #endif
         const bool cont = shade_bounce<INTEG, CLS, POOLED>(a.sc, st, a.fr, sobol_lds, ring, active, ps, prim, t, cnt, &df);
         if (active) {
@@ -1244,7 +1321,11 @@ struct iris_ctx {
     bool scene_is_lambert_constant = false;
     SceneDev sc = {};
     void *d_spheres = nullptr, *d_prim_info = nullptr, *d_bsdfs = nullptr, *d_spectra = nullptr, *d_lights = nullptr, *d_spec_over_pi = nullptr, *d_prim_kind = nullptr, *d_light_rec = nullptr;
-    uint32_t *d_xq = nullptr, *d_stack_hi = nullptr, *d_park = nullptr;
+    uint32_t *d_stack_hi = nullptr, *d_park = nullptr;
+    uint4 *d_kq = nullptr;
+    size_t kq_items = 0;
+    int64_t sort_kinds = 1;   // general classes: sort hits by BSDF kind through per-wave stacks in global memory (k_regwave's SORTED)
+    int n_bsdf_kinds = 0;     // distinct kinds among the uploaded scene's primitives
     size_t park_words = 0;
     unsigned char *d_sky = nullptr;
     size_t sky_cap = 0;
@@ -1252,8 +1333,6 @@ struct iris_ctx {
     int64_t work_run = 0;               // items per claim (0: chosen per launch)
     int64_t sky_mask = 1;
     size_t stack_hi_words = 0;
-    size_t xq_waves = 0;
-    int64_t x_park_max = 24, x_fire = 110;
     void *d_bvh_nodes = nullptr, *d_bvh_spheres = nullptr, *d_bvh_prim = nullptr, *d_bvh_q = nullptr;
     void *d_env_texels = nullptr, *d_env_func = nullptr, *d_env_cond = nullptr, *d_env_marg = nullptr;
     float *d_up_coeff = nullptr, *d_up_scale = nullptr;  // UpsampleTable resident in HBM (iris_upsample_table_upload)
@@ -1608,7 +1687,8 @@ struct Workspace {
     float4 *film_acc = nullptr;        // running per-pixel sums between sample-range chunks (chunked renders only)
     unsigned char *sky = nullptr;
     unsigned long long *counters = nullptr, *work_cursor = nullptr;
-    uint32_t *xq = nullptr, *stack_hi = nullptr, *park = nullptr;
+    uint32_t *stack_hi = nullptr, *park = nullptr;
+    uint4 *kq = nullptr;
 };
 
 int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p, float *d_out, hipStream_t stream, bool no_alloc = false) {
@@ -1632,6 +1712,9 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     if (no_alloc) per_cu = std::min<int64_t>(per_cu, 4);  // a CU holds at most 4 of these workgroups; a smaller grid keeps the per-wave queues small
     const bool pooled = reg && c->sc.n_bvh_nodes && c->scene_class == IRIS_CLS_LAMBERT_CONSTANT;  // k_regwave<.., LAMBERT_CONSTANT, true>: the ray pool
     if (pooled) per_cu = std::min<int64_t>(per_cu, no_alloc ? 3 : 4);  // three are resident; every lane of the grid owns a parking area in global memory (the static workspace pays for residents only)
+    // k_regwave's SORTED: stacks of path records per BSDF kind, when the scene holds more than one kind
+    const bool sorted = reg && c->scene_class != IRIS_CLS_LAMBERT_CONSTANT && c->sort_kinds && c->n_bsdf_kinds > 1 && !no_alloc;
+    if (sorted) per_cu = std::min<int64_t>(per_cu, 4);    // three are resident; every wave of the grid owns its stacks in global memory
     if (per_cu == 0) {
         const size_t dyn = (size_t)sphere_cap_for(c) * sizeof(float4);
         switch (p->integrator) {
@@ -1651,7 +1734,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
     // sky mask: register kernel on a short list without an environment map
     const bool use_sky = c->sky_mask && reg && !c->sc.n_bvh_nodes && c->sc.env_w == 0u && p->spp_count != 0u && p->max_depth != 0u;
     const size_t stack_hi_words = (reg && !wfq && c->sc.n_bvh_nodes && c->bvh_depth > reg_stack_lds) ? (size_t)blocks * BLOCK * (c->bvh_depth - reg_stack_lds) : 0;
-    const size_t xq_waves = (reg && c->scene_class == IRIS_CLS_GENERAL) ? (size_t)blocks * (BLOCK / 64) : 0;
+    const size_t kq_items = sorted ? (size_t)blocks * (BLOCK / 64) * KQ_KINDS * KQ_FIELDS * KQ_CAP : 0;  // uint4 each
     const size_t park_words = (pooled && !wfq) ? (size_t)blocks * BLOCK * IRIS_WALK_WORDS : 0;
     uint32_t spp_per_chunk;
     Workspace ws;
@@ -1664,9 +1747,10 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         const size_t o_counters = carve(IRIS_N_COUNTERS * sizeof(unsigned long long)), o_cursor = carve(sizeof(unsigned long long));
-        const size_t o_sky = carve(use_sky ? npix : 0), o_xq = carve(xq_waves * PQ_FIELDS * XQ_CAP * sizeof(uint32_t));
+        const size_t o_sky = carve(use_sky ? npix : 0);
         const size_t o_stack = carve(stack_hi_words * sizeof(uint32_t));
         const size_t o_park = carve(park_words * sizeof(uint32_t));
+        const size_t o_kq = carve(kq_items * sizeof(uint4));
         const size_t o_results = carve((size_t)p->spp_count * npix * sizeof(XyzResult));
         if (off > IRIS_NOALLOC_SCRATCH_BYTES || (uint64_t)p->spp_count * npix > (1ull << 31))
             return fail(c, IRIS_E_LIMIT, "iris_render_device_noalloc: this render needs " + std::to_string(off) + " bytes of workspace (12 per camera sample + " +
@@ -1676,9 +1760,9 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         ws.counters = (unsigned long long *)(base + o_counters);
         ws.work_cursor = (unsigned long long *)(base + o_cursor);
         ws.sky = base + o_sky;
-        ws.xq = (uint32_t *)(base + o_xq);
         ws.stack_hi = (uint32_t *)(base + o_stack);
         ws.park = (uint32_t *)(base + o_park);
+        ws.kq = (uint4 *)(base + o_kq);
         ws.results = (XyzResult *)(base + o_results);
         spp_per_chunk = std::max<uint32_t>(p->spp_count, 1u);
     } else {
@@ -1716,12 +1800,12 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
             if ((rc = dev_alloc(c, &c->d_park, park_words))) return rc;
             c->park_words = park_words;
         }
-        if (c->xq_waves < xq_waves) {  // second hit queue of the general classes
-            dev_free(c->d_xq);
-            c->d_xq = nullptr;
-            c->xq_waves = 0;
-            if ((rc = dev_alloc(c, &c->d_xq, xq_waves * PQ_FIELDS * XQ_CAP))) return rc;
-            c->xq_waves = xq_waves;
+        if (c->kq_items < kq_items) {  // per-wave stacks of path records by BSDF kind (general classes)
+            dev_free(c->d_kq);
+            c->d_kq = nullptr;
+            c->kq_items = 0;
+            if ((rc = dev_alloc(c, &c->d_kq, kq_items))) return rc;
+            c->kq_items = kq_items;
         }
         if (use_sky && c->sky_cap < npix) {
             dev_free(c->d_sky);
@@ -1735,9 +1819,9 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         ws.sky = c->d_sky;
         ws.counters = c->d_counters;
         ws.work_cursor = c->d_work_cursor;
-        ws.xq = c->d_xq;
         ws.stack_hi = c->d_stack_hi;
         ws.park = c->d_park;
+        ws.kq = c->d_kq;
     }
     HIP_TRY(c, hipMemsetAsync(ws.counters, 0, IRIS_N_COUNTERS * sizeof(unsigned long long), stream));
     if (use_sky) {
@@ -1773,7 +1857,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         a.items_per_block = ((a.n_items + blocks * 64u - 1) / (blocks * 64u)) * 64u;  // whole runs of 64
         a.slots_per_block = spb;
         a.sphere_cap = sphere_cap_for(c);
-        a.xq = ws.xq;
+        a.kq = sorted ? ws.kq : nullptr;  // nullptr: the kernel sorts nothing and never touches the stacks
         a.sky = use_sky ? ws.sky : nullptr;
         a.stack_hi = ws.stack_hi;
         a.park = ws.park;
@@ -1787,8 +1871,6 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         const uint32_t run_cap = c->sc.n_bvh_nodes ? 256u : (c->scene_class == IRIS_CLS_LAMBERT_CONSTANT ? 2048u : 512u);
         a.work_run = c->work_run ? (uint32_t)c->work_run : std::min<uint32_t>(run_cap, std::max<uint32_t>(64u, (a.n_items / (blocks * (BLOCK / 64u) * 8u)) & ~63u));
         if (reg || wfq) HIP_TRY(c, hipMemsetAsync(ws.work_cursor, 0, sizeof(unsigned long long), stream));
-        a.x_park_max = (uint32_t)c->x_park_max;
-        a.x_fire = (uint32_t)c->x_fire;
         HIP_TRY(c, hipEventRecord(c->ev0, stream));
         switch (p->integrator) {
         case IRIS_INT_HWSS_NAIVE: rc = launch_chunk<IRIS_INT_HWSS_NAIVE>(c, a, blocks, stream); break;
@@ -1826,7 +1908,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
         std::fprintf(stderr, "[phase timers] extend %.1f%% generate %.1f%% refill %.1f%% shade %.1f%% (wave-cycles %.3g)\n", 100.0 * t[4] / tot,
                      100.0 * t[5] / tot, 100.0 * t[6] / tot, 100.0 * t[7] / tot, tot);
         std::fprintf(stderr, "[phase timers] shade iterations %llu, lanes holding a hit per iteration %.2f of 64\n", t[9], (double)t[8] / (double)std::max(1ull, t[9]));
-        std::fprintf(stderr, "[phase timers] mixed iterations %llu: %.2f lanes shaded, %.2f of them of the second kind\n", t[11],
+        std::fprintf(stderr, "[phase timers] sorted iterations %llu: %.2f records moved out, %.2f taken from the stacks\n", t[11],
                      (double)t[12] / (double)std::max(1ull, t[11]), (double)t[13] / (double)std::max(1ull, t[11]));
         {
             unsigned long long g[8] = {};
@@ -1835,7 +1917,7 @@ int render_impl(iris_ctx *c, const iris_camera *cam, const iris_render_params *p
                          g[0], (double)g[1] / std::max(1ull, g[0]), (double)g[2] / std::max(1ull, g[0]), (double)g[3] / std::max(1ull, g[2]),
                          (double)g[4] / std::max(1ull, g[0]), (double)g[5] / std::max(1ull, g[4]), (double)g[6] / std::max(1ull, g[0]), (double)g[7] / std::max(1ull, g[6]));
         }
-        std::fprintf(stderr, "[phase timers] second-kind lanes per mixed iteration: microfacet %.2f specular %.2f fresnel %.2f\n", (double)t[14] / (double)std::max(1ull, t[11]),
+        std::fprintf(stderr, "[phase timers] share of sorted iterations by kind: microfacet %.2f specular %.2f fresnel %.2f\n", (double)t[14] / (double)std::max(1ull, t[11]),
                      (double)t[15] / (double)std::max(1ull, t[11]), (double)t[16] / (double)std::max(1ull, t[11]));
     }
 #endif
@@ -1901,7 +1983,7 @@ void iris_ctx_destroy(iris_ctx *c) {
     dev_free(c->d_bvh_nodes); dev_free(c->d_bvh_spheres); dev_free(c->d_bvh_prim); dev_free(c->d_bvh_q);
     dev_free(c->d_env_texels); dev_free(c->d_env_func); dev_free(c->d_env_cond); dev_free(c->d_env_marg);
     dev_free(c->d_up_coeff); dev_free(c->d_up_scale);
-    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_xq); dev_free(c->d_stack_hi); dev_free(c->d_park); dev_free(c->d_sky); dev_free(c->d_work_cursor);
+    dev_free(c->d_counters); dev_free(c->d_live); dev_free(c->d_results); dev_free(c->d_film_acc); dev_free(c->d_kq); dev_free(c->d_stack_hi); dev_free(c->d_park); dev_free(c->d_sky); dev_free(c->d_work_cursor);
     if (c->h_live) (void)hipHostFree(c->h_live);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1932,13 +2014,9 @@ int iris_ctx_set_option(iris_ctx *c, const char *key, int64_t value) {
     } else if (k == "bvh_min_prims") {
         if (value < 0) return fail(c, IRIS_E_ARG, "bvh_min_prims must be >= 0");
         c->bvh_min_prims = value;  // takes effect at the next iris_scene_upload
-    } else if (k == "x_park_max") {
-        // at most 64: once every lane of a wave waits with such a hit, the mixed iteration is the only way forward
-        if (value < 1 || value > 64) return fail(c, IRIS_E_ARG, "x_park_max out of range [1, 64]");
-        c->x_park_max = value;
-    } else if (k == "x_fire") {
-        if (value < 1 || value > 129) return fail(c, IRIS_E_ARG, "x_fire out of range [1, 129]");
-        c->x_fire = value;
+    } else if (k == "sort_kinds") {
+        if (value < 0 || value > 1) return fail(c, IRIS_E_ARG, "sort_kinds must be 0 or 1");
+        c->sort_kinds = value;
     } else if (k == "sky_mask") {
         c->sky_mask = value ? 1 : 0;
     } else if (k == "bvh_leaf") {
@@ -2060,7 +2138,16 @@ int iris_scene_upload(iris_ctx *c, const iris_scene_desc *s) {
     HIP_TRY(c, up(&c->d_spec_over_pi, over_pi.data(), sizeof(float) * over_pi.size()));
     c->sc.spec_over_pi = (const float *)c->d_spec_over_pi;
     std::vector<unsigned char> kind(s->n_prims, 0);
-    for (uint32_t i = 0; i < s->n_prims; i++) kind[i] = (s->prim_material[i] >= 0 && s->bsdfs[s->prim_material[i]].kind != IRIS_BSDF_LAMBERTIAN) ? 1 : 0;
+    for (uint32_t i = 0; i < s->n_prims; i++) {  // the BSDF's kind; no material and the absorbing BSDF count as Lambertian (0): the cheap group
+        const uint32_t k = s->prim_material[i] >= 0 ? s->bsdfs[s->prim_material[i]].kind : 0u;
+        kind[i] = (unsigned char)(k < KQ_KINDS ? k : 0u);
+    }
+    {
+        bool seen[KQ_KINDS] = {};
+        for (unsigned char k : kind) seen[k] = true;
+        c->n_bsdf_kinds = 0;
+        for (bool b : seen) c->n_bsdf_kinds += b ? 1 : 0;
+    }
     HIP_TRY(c, up(&c->d_prim_kind, kind.data(), kind.size()));
     c->sc.prim_kind = (const unsigned char *)c->d_prim_kind;
     c->sc.spheres = (const float4 *)c->d_spheres;

@@ -326,32 +326,45 @@ def test_sample_ranges_and_schedules_do_not_change_the_film(gpu, iris_trig):
     assert np.array_equal(bits(big), bits(wantb)) and big.any()
 
 
-def test_second_kind_scheduling_knobs_do_not_change_the_film(gpu, iris_trig):
-    """x_park_max / x_fire (register-resident kernel, general class) only decide WHEN hits on non-Lambertian surfaces are
-    shaded; at their extreme values -- a mixed iteration as soon as one lane waits, or only when all 64 do -- film and
-    counters stay the defaults' bit for bit, and a wave full of waiting lanes still makes progress (S3 is mostly such
-    surfaces).  Values outside the documented ranges are refused."""
+@pytest.mark.parametrize("integrator", [0, 1, 2, 3])
+def test_sorting_hits_by_bsdf_kind_changes_no_bit(iris_trig, integrator):
+    """General-class scenes: every wave of the register-resident kernel moves hits between its lanes and per-kind stacks of
+    path records in global memory so that a shade iteration runs one BSDF's code (sort_kinds, default 1).  Which lane and
+    which iteration shade a bounce must change nothing: films and all four work counters equal the unsorted run's
+    (sort_kinds = 0) bit for bit and the oracle's, for S3 (four kinds, depth 32: paths change kind at nearly every bounce),
+    S3 under an environment map, and a random soup of 150 spheres of every kind under a hierarchy; with one workgroup per
+    CU (long-lived waves: deep stacks) and with runs of 64 items; at a size where every stack fills and drains many times."""
     import iris_amd
-    from iris_amd import Render, Scene
-    from iris_amd.ffi import IrisError
-    scene = Scene.glossy_dielectric()
-    flat = gpu.upload(scene)
-    r = Render(128, 96, 12, scene, max_depth=32)
-    base = gpu.render_film(r)
-    bs = gpu.stats()
-    want, _ = oracle_film(iris_trig, flat, 128, 96, 12, max_depth=32)
-    assert np.array_equal(bits(base), bits(want))
-    for opts in ({"x_park_max": 1}, {"x_park_max": 64}, {"x_fire": 1}, {"x_fire": 129}, {"x_park_max": 64, "x_fire": 129},
-                 {"x_park_max": 1, "x_fire": 1}, {"x_park_max": 64, "x_fire": 129, "reg_blocks_per_cu": 1}):
-        with iris_amd.HipWavefront(0, **opts) as g2:
-            g2.upload(scene)
-            film = g2.render_film(r)
-            st = g2.stats()
-            assert np.array_equal(bits(film), bits(base)), opts
-            assert (st.samples, st.bounces, st.rays, st.sphere_tests) == (bs.samples, bs.bounces, bs.rays, bs.sphere_tests), opts
-    for key, bad in (("x_park_max", 0), ("x_park_max", 65), ("x_fire", 0), ("x_fire", 130)):
-        with pytest.raises(IrisError):
-            gpu.set_option(key, bad)
+    from iris_amd import EnvMap, Render, Scene, UpsampleTable
+    from test_gpu_fuzz import random_scene
+    table = UpsampleTable(os.path.join(GOLD, "srgb_res16.coeff"))
+    scenes = {"s3": Scene.glossy_dielectric(), "s3env": Scene.glossy_dielectric(),
+              "soup": random_scene(np.random.RandomState(77), table, 150, False)}
+    scenes["s3env"].env_map = EnvMap.sky(table, 64, 64)
+    for name, scene in scenes.items():
+        w, h, spp = (160, 96, 8) if name != "soup" else (96, 64, 4)
+        r = Render(w, h, spp, scene, max_depth=32, integrator=integrator)
+        films, stats = {}, {}
+        for tag, opts in (("sorted", {}), ("unsorted", {"sort_kinds": 0}), ("one workgroup per CU", {"reg_blocks_per_cu": 1}),
+                          ("short runs", {"work_run": 64})):
+            with iris_amd.HipWavefront(0, **opts) as g:
+                flat = g.upload(scene)
+                films[tag] = g.render_film(r)
+                st = g.stats()
+                stats[tag] = (st.samples, st.bounces, st.rays, st.sphere_tests)
+                assert st.kernel == 2, (name, tag)
+        want, ctr = oracle_film(iris_trig, flat, w, h, spp, max_depth=32, integrator=integrator)
+        for tag in films:
+            assert np.array_equal(bits(films[tag]), bits(want)), (name, tag)
+            assert stats[tag] == stats["sorted"], (name, tag)
+        assert stats["sorted"][:3] == (ctr.samples, ctr.bounces, ctr.rays), name
+        if name != "soup":  # (under a hierarchy the kernel makes fewer sphere tests than the oracle's list scan)
+            assert stats["sorted"][3] == ctr.sphere_tests, name
+    with iris_amd.HipWavefront(0) as g:
+        from iris_amd.ffi import IrisError
+        for bad in (-1, 2):
+            with pytest.raises(IrisError):
+                g.set_option("sort_kinds", bad)
 
 
 def test_film_vs_libm_trig_oracle(gpu, libm_trig):
