@@ -195,7 +195,7 @@ IRIS_DEV double trig_kcos(double r, bool pin) {
 }
 // sin and cos of the same argument share the reduction and both kernels.
 IRIS_DEV void iris_sincos(float x, float &s_out, float &c_out, bool pin = true) {
-#if IRIS_RELAXED
+#if IRIS_RELAXED || defined(IRIS_EXPERIMENT_HW_SINCOS)  // (the second: a timing experiment only -- what ALL of the binary64 evaluation costs)
     // relaxed build: the hardware's sine and cosine (arguments in revolutions; absolute error about 1e-6) instead of ~45 binary64
     // instructions.  Every caller passes an angle in [-pi, 2 pi] and normalises the direction it builds from the result.
     (void)pin;

@@ -425,7 +425,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
     // SORTED: this wave's stacks, their fill (wave-uniform), the BSDF kind of the hit a lane holds
     uint4 *const kq = SORTED ? a.kq + (size_t)(blockIdx.x * (BLOCK / 64) + threadIdx.x / 64) * (KQ_KINDS * KQ_FIELDS * KQ_CAP) : nullptr;
     uint32_t kc[KQ_KINDS] = {0u, 0u, 0u, 0u};
-    uint32_t kind = 0u;
     // (no stacks -- the scene holds one kind only, option sort_kinds = 0, or the entry point that may not allocate: every hit counts as kind 0,
     // nothing is ever moved, and an iteration shades whatever the lanes hold)
     const bool sort_on = SORTED && a.kq != nullptr;
@@ -527,7 +526,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                     prim = prim_new;
                     if (prim >= 0) {
                         lane_state = LANE_HIT;
-                        if (SORTED) kind = kind_of(prim);
                     } else {  // `None => break` (hwss_naive.rs:41-44)
                         path_miss<INTEG, CLS>(a.sc, ps);
                         store_result(a, item, path_xyz<INTEG>(ps));
@@ -540,7 +538,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
         // ---- generate: camera samples, 64 at a time, until a wave's worth of primary hits is queued ----
         // (SORTED: hits in flight -- in lanes, in the stacks, in the primary queue -- stay below KQ_CAP, which is what bounds every stack)
         uint32_t in_flight = 0u;
-        if (SORTED) in_flight = (uint32_t)__popcll(__ballot(lane_state == LANE_HIT)) + q_count + kc[0] + kc[1] + kc[2] + kc[3];
+        if (SORTED && sort_on) in_flight = (uint32_t)__popcll(__ballot(lane_state == LANE_HIT)) + q_count + kc[0] + kc[1] + kc[2] + kc[3];
         while (work_left && q_count < PQ_LOW && (!SORTED || in_flight < KQ_LOW)) {
             if (w_next >= w_lim) {
                 unsigned long long claim = 0ull;  // 64 bits: every wave asks once too often, and grids and runs can be made large
@@ -632,7 +630,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
         }
         IRIS_PHASE(1);
         // ---- SORTED: pick the BSDF kind of this iteration, move the other kinds' hits out and hits of that kind in ----
-        if (SORTED) {
+        if (SORTED && sort_on) {
+            const uint32_t kind = lane_state == LANE_HIT ? kind_of(prim) : 0u;  // (looked up here, one byte: not worth a register across the shade phase)
             uint32_t best = 0u, best_score = 0u, sel_count = 0u;
 #pragma unroll
             for (uint32_t j = 0; j < KQ_KINDS; j++) {
@@ -678,7 +677,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                     ps.smp.scramble = f5.x; ps.smp.index = f5.y; item = f5.z; ps.smp.draws = f5.w;
                     sampler_rewind(ps.smp);  // this lane's ring holds another path's values
                     prim = (int)f6.x; t = __uint_as_float(f6.y);
-                    kind = best;
                     lane_state = LANE_HIT;
                 }
 #pragma unroll
@@ -695,18 +693,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                     path_begin(a.cam, cs, q[1][e], ring, ps);
                     t = __uint_as_float(q[7][e]);
                     prim = (int)q[8][e];
-                    kind = 0u;
                     lane_state = LANE_HIT;
                 }
                 q_head = (q_head + n_q) % PQ_CAP;
                 q_count -= n_q;
+                // lanes that keep a hit of another kind (none of the chosen kind was left to take their place) sit this iteration out
+                if (other && !evict) lane_state = LANE_HITX;
                 __builtin_amdgcn_wave_barrier();
             }
-            // lanes that hold a hit of another kind (none of the chosen kind was left to take their place) sit this iteration out
-            if (lane_state == LANE_HIT && kind != best) lane_state = LANE_HITX;
         }
         // ---- refill: lanes without a path take a queued primary hit ----
-        if (!SORTED) {
+        if (!SORTED || !sort_on) {
             const bool dead = lane_state == LANE_DEAD;
             const unsigned long long dmask = __ballot(dead);
             const uint32_t n_dead = (uint32_t)__popcll(dmask);
