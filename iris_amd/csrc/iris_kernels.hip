@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
 //     bounce (apply_deferred: the reference's order of additions), shades the next bounce (shade_bounce<.., 2>: no traversal
 //     code) and appends up to three rays to the ray queue -- extension ray, light-sample query, BSDF-sample query; a slot whose
 //     path has ended (miss, absorption, roulette, depth) adds what was deferred, stores the sample's XYZ and starts the next camera
-//     sample of the launch's item counter in the same lane; rays are appended compacted (one atomic per workgroup and pass);
+//     sample of the launch's item counter in the same lane; a tile's rays go, compacted, to the tile's own region of the queue;
 //   * k_wfq_trace answers the queue: (t, primitive) per ray into the result array beside it, read by the next k_wfq_shade.
 // Two ray queues alternate (pass p reads queue p & 1 and fills the other); the counters a pass needs at zero are cleared by the
 // kernel before it.  The host launches trace/shade pairs in batches and reads the number of live paths after each batch; several
