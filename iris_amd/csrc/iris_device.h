@@ -1207,7 +1207,12 @@ IRIS_DEV void wfq_prepare(const SceneDev &sc, const Ray &ray, bool any, float li
 // atomic to append).  A wave claims one region at a time from `cursor` and hands its rays to its lanes as they fall idle.
 // (Tried and dropped: two lanes per ray, each fetching and testing one child and swapping results through DPP -- bit-exact, but
 // 124 ms against 109 ms for the trace kernels of config D: the vector L1 serves about one 16-byte lane request per cycle whichever
-// lane asks, so the requests per ray, not the lanes, are what has to shrink -- see the compressed nodes, box_entry_q.)
+// lane asks, so the requests per ray, not the lanes, are what has to shrink -- see the compressed nodes, box_entry_q.
+// Also tried and dropped, with the compressed nodes: TWO RAYS PER LANE -- a lane whose working ray is at the other kind of node than
+// the round's exchanges it with its second ray (twelve v_swap_b32; origin and direction re-read from the queue at the leaves), so that
+// a lane idles only when neither ray can take part: bit-exact, 116.9 ms (72 VGPR, 7 waves) / 119.3 ms (80 VGPR, 6 waves) against
+// 113.3 ms.  The lanes were not the limit: with the texture-data path 83 % and the VALU 60-70 % busy, more lanes per step only
+// queue up behind the same L1.)
 #define IRIS_WFQ_REGION 768u
 #ifdef IRIS_WFQ_STATS  // diagnostic build: rounds and the lanes busy in them -- fetches, rays fetched, inner rounds, lanes at each inner step, leaf rounds, lanes, all rounds, lanes holding a ray
 __device__ unsigned long long g_wfq_stats[8];
