@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "iris_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:const\s+char\s*\*|int|void|float|uint32_t|size_t)\s*\*?\s*(iris_\w+)\s*\(", header, re.M))
     assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
-    for path in (ffi.LIB_PATH, ffi.LIB_RELAXED_PATH):  # the exact build and the opt-in relaxed build of the same ABI
+    for path in (ffi.LIB_PATH, ffi.LIB_RELAXED_PATH, ffi.LIB_DEBUG_PATH):  # the exact build, the opt-in relaxed build and the debug-invariants build: one ABI
         L = C.CDLL(path)
         for name in declared:
             assert hasattr(L, name), (path, name)
