@@ -681,6 +681,43 @@ def radiance(prims, lights, ray, wl, smp, trace, hwss=True, max_depth=15):  # hw
     return rad if hwss else [rad[0], ZERO, ZERO, ZERO]                 # swss_naive.rs:87
 
 
+def radiance_slow(prims, lights, ray, wl, smp, trace, hwss=True, max_depth=15):  # hwss_slow.rs:28-84 / swss_slow.rs:28-82
+    """The integrators without next-event estimation: emission is collected wherever a path lands on a light (HWSS: weighted by
+    balance_heuristic_1 of the path pdfs), the BSDF sample is the only continuation."""
+    rad, throughput, path_pdfs = splat(0.0), splat(1.0), splat(1.0)
+    for bounces in range(max_depth):
+        closest_t, closest = scan(prims, ray)                          # scene.rs:116-132
+        if closest is None:
+            break
+        prim_index, hit = closest
+        trace["hit_prim"].append(prim_index)
+        trace["hit_t"].append(closest_t)
+        prim = prims[prim_index]
+        if prim.light is not None:                                     # hwss_slow.rs:47-49 / swss_slow.rs:46-48: at every bounce
+            if hwss:
+                rad = add4(rad, scale4(mul4(throughput, splat(prim.light)), balance_heuristic_1(path_pdfs)))
+            else:
+                rad = add4(rad, mul4(throughput, splat(prim.light)))
+        bsdf = prim.material
+        if bsdf is None:
+            break
+        shading_wo = world_to_shading(hit, -ray.d)
+        wi, bsdf_values, bsdf_pdfs = bsdf.sample(shading_wo, wl, smp)
+        cos_theta_ = abs(wi.z)
+        if bsdf_pdfs[0] == ZERO or cos_theta_ == ZERO:
+            break
+        throughput = mul4(throughput, div4s(scale4(bsdf_values, cos_theta_), bsdf_pdfs[0]))
+        if hwss:
+            path_pdfs = mul4(path_pdfs, bsdf_pdfs)
+        if bounces >= MIN_DEPTH:
+            p = fmin(sum4(throughput), F(0.95))
+            if smp.gen_0_1() > p:
+                break
+            throughput = [t / p for t in throughput]
+        ray = Ray.spawn(hit.point, shading_to_world(hit, wi), hit.normal)
+    return rad if hwss else [rad[0], ZERO, ZERO, ZERO]                 # swss_slow.rs:81
+
+
 # ------------------------------------------------------------------ spectrum/wavelength.rs, sample.rs, color.rs
 def rotate_n(hero, n):  # wavelength.rs:55-64
     lam = hero + (F(470.0) / F(4.0)) * F(n)
@@ -726,11 +763,11 @@ def camera_sample(x, y, sample_index, width, height, seed, cam_pos, m):
     return smp, wl, Ray.new(origin, target - origin)
 
 
-def trace_sample(x, y, sample_index, width, height, seed, cam_pos, m, cmf, scene, hwss=True, max_depth=15):
+def trace_sample(x, y, sample_index, width, height, seed, cam_pos, m, cmf, scene, hwss=True, max_depth=15, slow=False):
     prims, lights = scene
     smp, wl, ray = camera_sample(x, y, sample_index, width, height, seed, cam_pos, m)
     tr = {"hit_prim": [], "hit_t": []}
-    rad = radiance(prims, lights, ray, wl, smp, tr, hwss, max_depth)
+    rad = (radiance_slow if slow else radiance)(prims, lights, ray, wl, smp, tr, hwss, max_depth)
     tr.update(hero=wl, ray_d=ray.d.tolist(), radiance=rad, xyz=to_xyz(rad, wl, cmf), draws=smp.draws)
     return tr
 
@@ -738,7 +775,8 @@ def trace_sample(x, y, sample_index, width, height, seed, cam_pos, m, cmf, scene
 def trace_set(xys, integrators, width, height, cam_pos, m, cmf, scene, max_depth, pad):
     out = {k: [] for k in ("hero", "ray_d", "radiance", "xyz", "n_hits", "draws", "hit_prim", "hit_t")}
     for (x, y, s), integ in zip(xys, integrators):
-        tr = trace_sample(int(x), int(y), int(s), width, height, 123456789, cam_pos, m, cmf, scene, hwss=(integ == 0), max_depth=max_depth)
+        # enum iris_integrator: 0 HwssNaive, 1 HwssSlow, 2 SwssNaive, 3 SwssSlow
+        tr = trace_sample(int(x), int(y), int(s), width, height, 123456789, cam_pos, m, cmf, scene, hwss=(integ < 2), max_depth=max_depth, slow=bool(integ & 1))
         out["hero"].append(tr["hero"]); out["ray_d"].append(tr["ray_d"]); out["radiance"].append(tr["radiance"]); out["xyz"].append(tr["xyz"])
         out["n_hits"].append(len(tr["hit_prim"])); out["draws"].append(tr["draws"])
         out["hit_prim"].append((tr["hit_prim"] + [-1] * pad)[:pad]); out["hit_t"].append((tr["hit_t"] + [ZERO] * pad)[:pad])
@@ -796,6 +834,24 @@ def main():
         for p_ in row[:n]:
             kinds[p_] = kinds.get(p_, 0) + 1
     print("S3 bounce records by primitive (0 light, 1 dielectric, 2 ground, 3 GGX, 4 mirror):", dict(sorted(kinds.items())))
+    # ---- the integrators without next-event estimation (hwss_slow.rs, swss_slow.rs): 64 + 64 samples on the default scene at depth
+    # 15 and 64 + 64 on the glossy/dielectric scene at depth 32 -- paths find the light only by landing on it, so samples are aimed
+    # where that happens more often (near the light's reflection and through the dielectric)
+    if "--slow" in sys.argv or "--all" in sys.argv:
+        rng = np.random.RandomState(20271111)
+        for name, scene, depth, pad in (("traces_s1_slow_restated.npz", default_scene(), 15, 16),
+                                        ("traces_s3_slow_restated.npz", glossy_dielectric_scene(alpha), 32, 32)):
+            n = 512
+            xs = rng.randint(0, [width, height, 256], size=(n, 3)).astype(np.uint32)
+            xs[:, 1] = 230 + xs[:, 1] % 282                       # spheres and ground
+            near = np.arange(n) % 4 == 0                          # every fourth sample: at and around the light
+            xs[near, 0] = np.clip(255 + rng.randint(-40, 41, int(near.sum())), 0, width - 1)
+            xs[near, 1] = np.clip(40 + rng.randint(-40, 41, int(near.sum())), 0, height - 1)
+            integ = np.array([1] * (n // 2) + [3] * (n // 2), np.uint32)
+            o = trace_set(xs, integ, width, height, cam_pos, m, cmf, scene, depth, pad)
+            save(name, xs, integ, width, height, cam_pos, m, o, extra={"integrator": integ, "alpha": np.float32(alpha), "max_depth": np.uint32(depth)})
+            lit = int(np.sum(np.any(np.array(o["radiance"], np.float32) != 0, axis=1)))
+            print("   samples with radiance:", lit, "of", len(xs))
 
 
 if __name__ == "__main__":

@@ -247,6 +247,28 @@ def test_traces_match_the_independent_restatement_of_the_glossy_dielectric_scene
                 assert np.array_equal(bits(list(val)), bits(g[name][i])), (name, i)
 
 
+@pytest.mark.parametrize("name,scene_name", [("traces_s1_slow_restated.npz", "s1"), ("traces_s3_slow_restated.npz", "s3")])
+def test_traces_match_the_independent_restatement_of_the_integrators_without_light_sampling(gpu, name, scene_name):
+    """The GPU against tests/golden/traces_s{1,3}_slow_restated.npz: HwssSlow and SwssSlow, 256 camera samples each per scene,
+    computed in numpy float32 from hwss_slow.rs / swss_slow.rs (tests/golden/restate_path.py --slow)."""
+    from iris_amd import Camera, Render, Scene
+    g = np.load(os.path.join(GOLD, name))
+    scene = Scene.dummy() if scene_name == "s1" else Scene.glossy_dielectric()
+    gpu.upload(scene)
+    w, h = int(g["width"]), int(g["height"])
+    for integ in (1, 3):
+        sel = np.flatnonzero(g["integrator"] == integ)
+        r = Render(w, h, 256, scene, integrator=integ, max_depth=int(g["max_depth"]), camera=Camera([float(v) for v in g["cam_pos"]], np.float32(w) / np.float32(h)))
+        got = gpu.dbg_trace(r, g["xys"][sel])
+        for i, t in zip(sel, got):
+            n = int(g["n_hits"][i])
+            assert t.n_hits == n and t.draws == int(g["draws"][i]), i
+            assert list(t.hit_prim[:n]) == list(g["hit_prim"][i][:n])
+            assert np.array_equal(bits(list(t.hit_t[:n])), bits(g["hit_t"][i][:n]))
+            for field, val in (("hero", t.hero), ("ray_d", t.ray_d), ("radiance", t.radiance), ("xyz", t.xyz)):
+                assert np.array_equal(bits(list(val)), bits(g[field][i])), (field, i)
+
+
 def oracle_film(O, flat, w, h, spp, **kw):
     osc = O.OracleScene(flat)
     cam = O.camera_new([0, 0, 0], np.float32(w) / np.float32(h))

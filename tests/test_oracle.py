@@ -341,3 +341,34 @@ def test_oracle_matches_the_independent_restatement_of_the_glossy_dielectric_sce
         assert int(np.sum(g["n_hits"])) > 500 and np.any(g["radiance"][:192, 1:] != g["radiance"][:192, :1])  # dispersion: the wavelengths differ
     finally:
         oracle.set_trig_mode(oracle.TRIG_LIBM)
+
+
+@pytest.mark.parametrize("name,scene_name", [("traces_s1_slow_restated.npz", "s1"), ("traces_s3_slow_restated.npz", "s3")])
+def test_oracle_matches_the_independent_restatement_of_the_integrators_without_light_sampling(oracle, name, scene_name):
+    """tests/golden/traces_s{1,3}_slow_restated.npz (tests/golden/restate_path.py --slow): HwssSlow (hwss_slow.rs:28-84) and SwssSlow
+    (swss_slow.rs:28-82), 256 camera samples each, on the default scene (depth 15) and on the glossy/dielectric scene (depth 32),
+    restated in numpy float32 from the Rust text.  With the two naive integrators of the other files this pins all four integrators
+    on every BSDF kind the scenes hold.  Bit for bit: wavelengths, primary ray, primitive and t of every hit, draws, radiance, XYZ."""
+    g = np.load(os.path.join(GOLD, name))
+    from iris_amd import Scene
+    oracle.set_trig_mode(oracle.TRIG_IRIS)
+    try:
+        w, h = int(g["width"]), int(g["height"])
+        cam = oracle.camera_new([float(v) for v in g["cam_pos"]], np.float32(w) / np.float32(h))
+        flat = (Scene.dummy() if scene_name == "s1" else Scene.glossy_dielectric()).flatten()
+        sc = oracle.OracleScene(flat)
+        assert set(g["integrator"].tolist()) == {1, 3}
+        for i, (x, y, s) in enumerate(g["xys"]):
+            p = oracle.make_params(w, h, 256, integrator=int(g["integrator"][i]), max_depth=int(g["max_depth"]))
+            t = sc.trace(cam, p, int(x), int(y), int(s))
+            n = int(g["n_hits"][i])
+            assert t.n_hits == n and t.draws == int(g["draws"][i]), (i, x, y, s)
+            assert list(t.hit_prim[:n]) == list(g["hit_prim"][i][:n])
+            for field, got in (("hero", t.hero), ("ray_d", t.ray_d), ("radiance", t.radiance), ("xyz", t.xyz)):
+                assert np.array_equal(np.array(list(got), np.float32).view(np.uint32), g[field][i].view(np.uint32)), (field, i)
+            assert np.array_equal(np.array(list(t.hit_t[:n]), np.float32).view(np.uint32), g["hit_t"][i][:n].view(np.uint32)), i
+        lit = np.any(g["radiance"] != 0, axis=1)
+        assert lit[:256].sum() > 40 and lit[256:].sum() > 40  # both integrators found the light often enough to test the emission terms
+        assert np.all(g["radiance"][256:, 1:] == 0)           # SwssSlow returns the hero wavelength only (swss_slow.rs:81)
+    finally:
+        oracle.set_trig_mode(oracle.TRIG_LIBM)
