@@ -381,6 +381,20 @@ class Scene:
         return scene
 
     @classmethod
+    def enclosed(cls):
+        """A test scene for the light code the designed scenes do not reach: the default scene plus a GGX sphere, all INSIDE a second
+        light -- a sphere of radius 40 around the camera without a material (`add_light`, scene.rs:71-78: paths end on it).  Every
+        shading point lies inside that light, so its `sample` and `pdf` take the uniform-sphere branch (sphere.rs:83-95, :141-153),
+        and the light pick chooses between two lights (scene.rs:168-172)."""
+        scene = cls()
+        scene.add_emissive_material(Sphere((0.0, 2.3, 3.0), 1.0), LambertianBsdf(ConstantSpectrum(0.5)), ConstantSpectrum(3.0))
+        scene.add_material(Sphere((0.0, -0.2, 3.0), 1.0), LambertianBsdf(ConstantSpectrum(0.5)))
+        scene.add_material(Sphere((0.0, -101.5, 2.0), 100.0), LambertianBsdf(ConstantSpectrum(0.8)))
+        scene.add_material(Sphere((-2.2, -0.2, 3.5), 1.0), MicrofacetBsdf(ConstantSpectrum(0.9), 0.2, 0.2))
+        scene.add_light(Sphere((0.0, 0.0, 0.0), 40.0), ConstantSpectrum(0.25))
+        return scene
+
+    @classmethod
     def glossy_dielectric_env(cls, table, env_size=256):
         """BASELINE config E as named: the glossy/dielectric scene lit by an HDR environment map (procedural sky
         with a sun) in addition to the sphere light."""

@@ -596,6 +596,16 @@ def glossy_dielectric_scene(alpha):
     return prims, [0]
 
 
+def enclosed_scene(alpha):
+    """iris_amd.Scene.enclosed: the default scene and a GGX sphere inside a second light of radius 40 that has no material"""
+    prims = [Prim(Sphere((0.0, 2.3, 3.0), 1.0), Lambertian(0.5), F(3.0)),
+             Prim(Sphere((0.0, -0.2, 3.0), 1.0), Lambertian(0.5), None),
+             Prim(Sphere((0.0, -101.5, 2.0), 100.0), Lambertian(0.8), None),
+             Prim(Sphere((-2.2, -0.2, 3.5), 1.0), Microfacet(0.9, alpha, alpha), None),
+             Prim(Sphere((0.0, 0.0, 0.0), 40.0), None, F(0.25))]
+    return prims, [0, 4]
+
+
 def scan(prims, ray):
     """the loop shared by Scene::intersection / ray_hits_point / ray_hits_object (scene.rs:116-166):
     closest t > 0 in primitive order, strict `<`"""
@@ -852,6 +862,21 @@ def main():
             save(name, xs, integ, width, height, cam_pos, m, o, extra={"integrator": integ, "alpha": np.float32(alpha), "max_depth": np.uint32(depth)})
             lit = int(np.sum(np.any(np.array(o["radiance"], np.float32) != 0, axis=1)))
             print("   samples with radiance:", lit, "of", len(xs))
+    # ---- two lights, one of them around everything (iris_amd.Scene.enclosed): the uniform-sphere branches of Sphere::sample / pdf
+    # (sphere.rs:83-95, :141-153), the pick among several lights (scene.rs:168-172), a light without a material; all four integrators
+    if "--enclosed" in sys.argv or "--all" in sys.argv:
+        rng = np.random.RandomState(20281111)
+        n = 512
+        xs = rng.randint(0, [width, height, 256], size=(n, 3)).astype(np.uint32)
+        xs[n // 8:, 1] = 200 + xs[n // 8:, 1] % 312              # one eighth anywhere (the sky is the second light), the rest at the spheres and the ground
+        integ = np.array([0, 1, 2, 3] * (n // 4), np.uint32)
+        o = trace_set(xs, integ, width, height, cam_pos, m, cmf, enclosed_scene(alpha), 15, 16)
+        save("traces_enclosed_restated.npz", xs, integ, width, height, cam_pos, m, o, extra={"integrator": integ, "alpha": np.float32(alpha), "max_depth": np.uint32(15)})
+        kinds = {}
+        for row, k in zip(o["hit_prim"], o["n_hits"]):
+            for p_ in row[:k]:
+                kinds[p_] = kinds.get(p_, 0) + 1
+        print("   bounce records by primitive (0 small light, 1 sphere, 2 ground, 3 GGX, 4 enclosing light):", dict(sorted(kinds.items())))
 
 
 if __name__ == "__main__":

@@ -372,3 +372,33 @@ def test_oracle_matches_the_independent_restatement_of_the_integrators_without_l
         assert np.all(g["radiance"][256:, 1:] == 0)           # SwssSlow returns the hero wavelength only (swss_slow.rs:81)
     finally:
         oracle.set_trig_mode(oracle.TRIG_LIBM)
+
+
+def test_oracle_matches_the_independent_restatement_of_the_enclosed_scene(oracle):
+    """tests/golden/traces_enclosed_restated.npz (restate_path.py --enclosed): iris_amd.Scene.enclosed -- two lights, one of them a
+    sphere of radius 40 around camera and scene, without a material -- through all four integrators, 128 samples each.  Every
+    shading point lies inside the second light: Sphere::sample and Sphere::pdf take their uniform-sphere branches (sphere.rs:83-95,
+    :141-153), the light pick has two entries (scene.rs:168-172), paths end on a light without a material (hwss_naive.rs:46-49)."""
+    g = np.load(os.path.join(GOLD, "traces_enclosed_restated.npz"))
+    from iris_amd import Scene
+    oracle.set_trig_mode(oracle.TRIG_IRIS)
+    try:
+        w, h = int(g["width"]), int(g["height"])
+        cam = oracle.camera_new([float(v) for v in g["cam_pos"]], np.float32(w) / np.float32(h))
+        flat = Scene.enclosed().flatten()
+        assert [np.float32(b[3]) for b in flat.bsdfs if int(b[0]) == 1] == [g["alpha"]]
+        sc = oracle.OracleScene(flat)
+        assert sorted(set(g["integrator"].tolist())) == [0, 1, 2, 3]
+        for i, (x, y, s) in enumerate(g["xys"]):
+            p = oracle.make_params(w, h, 256, integrator=int(g["integrator"][i]), max_depth=int(g["max_depth"]))
+            t = sc.trace(cam, p, int(x), int(y), int(s))
+            n = int(g["n_hits"][i])
+            assert t.n_hits == n and t.draws == int(g["draws"][i]), (i, x, y, s)
+            assert list(t.hit_prim[:n]) == list(g["hit_prim"][i][:n])
+            for field, got in (("hero", t.hero), ("ray_d", t.ray_d), ("radiance", t.radiance), ("xyz", t.xyz)):
+                assert np.array_equal(np.array(list(got), np.float32).view(np.uint32), g[field][i].view(np.uint32)), (field, i)
+            assert np.array_equal(np.array(list(t.hit_t[:n]), np.float32).view(np.uint32), g["hit_t"][i][:n].view(np.uint32)), i
+        ends_on_big_light = sum(int(g["hit_prim"][i][int(g["n_hits"][i]) - 1] == 4) for i in range(len(g["xys"])) if g["n_hits"][i])
+        assert ends_on_big_light > 300 and int(np.sum(g["n_hits"])) > 1000
+    finally:
+        oracle.set_trig_mode(oracle.TRIG_LIBM)
