@@ -351,7 +351,7 @@ k_wavefront(WfArgs a) {
 // The expensive shade phase therefore runs with (nearly) every lane busy as long as work is left, and the
 // camera-sample code never runs for a handful of lanes.  No other wave touches a wave's queue, so no
 // synchronisation is needed.
-enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u, LANE_FIN = 4u };  // HITX: holds a hit of a BSDF kind that is not this iteration's; FIN: the path has ended, its last visibility query is still out
+enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u, LANE_FIN = 4u, LANE_DONE = 5u };  // HITX: holds a hit of a BSDF kind that is not this iteration's; FIN: the path has ended, its last visibility query is still out
 constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
 // General classes (SORTED), hits sorted by BSDF kind: a wave that shades hits on four BSDFs in one iteration runs ALL of that code for
 // a quarter of the lanes each, which is what halved the lane utilisation of such scenes (S3 52 %, config E 44 %).  So every wave owns one stack of whole path records per BSDF kind in global
@@ -528,9 +528,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                         lane_state = LANE_HIT;
                     } else {  // `None => break` (hwss_naive.rs:41-44)
                         path_miss<INTEG, CLS>(a.sc, ps);
-                        store_result(a, item, path_xyz<INTEG>(ps));
-                        lane_state = LANE_DEAD;
+                        lane_state = LANE_DONE;
                     }
+                }
+            }
+            // Finished paths -- the rays that just missed and the paths that ended in the last shade phase -- are converted to XYZ
+            // and stored HERE, together: one execution of the conversion per iteration for all of them instead of one in each phase
+            // for a part of the lanes each.
+            if (__ballot(lane_state == LANE_DONE) != 0ull) {
+                if (lane_state == LANE_DONE) {
+                    store_result(a, item, path_xyz<INTEG>(ps));
+                    lane_state = LANE_DEAD;
                 }
             }
         }
@@ -746,9 +754,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                 lane_state = LANE_RAY;
             } else if (POOLED && df.pending) {
                 lane_state = LANE_FIN;  // its direct-light term is added once its visibility query is back, then the result is stored
-            } else {
+            } else if (POOLED) {
                 store_result(a, item, path_xyz<INTEG>(ps));
                 lane_state = LANE_DEAD;
+            } else {
+                lane_state = LANE_DONE;  // stored after the next extend phase, with the paths whose ray misses there
             }
         }
         IRIS_PHASE(3);
