@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                         pn.thr = splat(1.0f); pn.ppdf = splat(1.0f); pn.rad = splat(0.0f);
                         kq_store(kind_new, slot, pn, new_item, prim_new, t_new);
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -707,6 +708,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(3)))
                 q_count -= n_q;
                 // lanes that keep a hit of another kind (none of the chosen kind was left to take their place) sit this iteration out
                 if (other && !evict) lane_state = LANE_HITX;
+                // the records stored above are read by OTHER lanes of this wave in a later iteration: same wave, same L1, in program
+                // order -- the fence keeps the compiler from moving memory operations across this point, the hardware needs nothing
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
         }
