@@ -344,18 +344,19 @@ k_wavefront(WfArgs a) {
 //              ray and intersect it.  Misses are finished on the spot (their radiance is exactly zero);
 //              hits are compacted (ballot + prefix sum) into the wave's queue as an 11-dword record.
 //              Runs whenever fewer than PQ_LOW records are queued, always with a full wave.
-//   extend:    lanes whose path survived the last bounce intersect their new ray.
+//   extend:    lanes whose path survived the last bounce intersect their new ray; then every path that has finished -- a ray that
+//              just missed, a path that ended in the last shade phase (LANE_DONE) -- is converted to XYZ and stored, in one step.
 //   refill:    lanes without a path pop a record each and become the first bounce of that path (general classes: hits are
 //              sorted by BSDF kind first, see below).
 //   shade:     every lane that holds a hit shades one bounce.
 // The expensive shade phase therefore runs with (nearly) every lane busy as long as work is left, and the
 // camera-sample code never runs for a handful of lanes.  No other wave touches a wave's queue, so no
 // synchronisation is needed.
-enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u, LANE_FIN = 4u, LANE_DONE = 5u };  // HITX: holds a hit of a BSDF kind that is not this iteration's; FIN: the path has ended, its last visibility query is still out
+enum : uint32_t { LANE_DEAD = 0u, LANE_RAY = 1u, LANE_HIT = 2u, LANE_HITX = 3u, LANE_FIN = 4u, LANE_DONE = 5u };  // HITX: holds a hit of a BSDF kind that is not this iteration's; FIN: the path has ended, its last visibility query is still out; DONE: finished, to be stored
 constexpr uint32_t PQ_FIELDS = 11;  // item, sample index, scramble, hero, d.xyz, t, prim, u2, u3
 // General classes (SORTED), hits sorted by BSDF kind: a wave that shades hits on four BSDFs in one iteration runs ALL of that code for
-// a quarter of the lanes each, which is what halved the lane utilisation of such scenes (S3 52 %, config E 44 %).  So every wave owns one stack of whole path records per BSDF kind in global
-// memory (L2-resident: only the tops are touched).  Before a shade iteration the wave picks ONE kind -- the one it can fill most
+// a quarter of the lanes each, which is what halved the lane utilisation of such scenes (S3 52 %, config E 44 %).  So every wave owns
+// one stack of whole path records per BSDF kind in global memory (L2-resident: only the tops are touched).  Before a shade iteration the wave picks ONE kind -- the one it can fill most
 // lanes with -- moves the hits of the other kinds out of its lanes into their stacks and takes hits of the chosen kind in, so the
 // iteration runs one BSDF's code with (nearly) every lane instead of four BSDFs' code with a quarter of the lanes each.  A path is a
 // function of (pixel, sample index) only, so which lane and which iteration shade a bounce changes no value.  A record: ray origin +
